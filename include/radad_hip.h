@@ -1,0 +1,203 @@
+/*
+ * radad_hip.h -- C ABI of libradad_hip.so: the MI355X (gfx950) implementation of RADAD's
+ * segment -> embed -> retrieve hot path.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; no torch / C++ types cross this boundary.
+ *   - pointers named *_dev are DEVICE pointers (e.g. torch.Tensor.data_ptr()); *_host are host pointers.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Kernels are enqueued on it
+ *     and the call returns without synchronising unless the comment says otherwise.
+ *   - every function returns 0 on success and a negative RADAD_E* code on failure; the message for the
+ *     calling thread is available from radad_last_error().
+ *   - handles are opaque.  A handle may be searched/reconstructed from several threads (calls are
+ *     serialised internally); add/load/destroy must not race with anything else.
+ *
+ * Each group cites the reference interface (file:line under the RADAD repository) it replaces.
+ */
+#ifndef RADAD_HIP_H
+#define RADAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RADAD_ABI_VERSION 1
+
+/* error codes */
+#define RADAD_OK 0
+#define RADAD_EINVAL (-1)   /* bad argument (maps to ValueError in the Python mirror)      */
+#define RADAD_EHIP (-2)     /* a HIP runtime call failed                                    */
+#define RADAD_ENOMEM (-3)   /* device or host allocation failed                             */
+#define RADAD_EIO (-4)      /* save/load failed                                             */
+#define RADAD_ESTATE (-5)   /* handle in the wrong state (e.g. search on an empty index)   */
+
+/* metric: what faiss.IndexFlatL2 / IndexFlatIP / IndexFlatIP+normalise compute
+ * (vector_database.py:61-64, :97, :100-105) */
+#define RADAD_METRIC_L2 0      /* squared Euclidean distance, ascending                    */
+#define RADAD_METRIC_IP 1      /* inner product, descending                                */
+#define RADAD_METRIC_COSINE 2  /* rows and queries L2-normalised (x/(|x|+1e-12)), then IP  */
+
+/* pooling mode (config.tpp_pooling_type, pooling.py:74-80) */
+#define RADAD_POOL_MAX 0
+#define RADAD_POOL_AVG 1
+
+int radad_abi_version(void);
+const char* radad_last_error(void);
+/* number of visible HIP devices, or a negative error code */
+int radad_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Vector store + brute-force kNN.
+ * Replaces the faiss index object that vector_database.py keeps in `self.index`:
+ *   create   -> faiss.IndexFlatL2/IP(dimension)                 vector_database.py:56-97
+ *   add      -> index.add(batch) after _maybe_normalize          vector_database.py:100-105,118,138
+ *   ntotal   -> index.ntotal                                     vector_database.py:151,169; pipeline.py:465
+ *   search   -> index.search(q, k)                               vector_database.py:181
+ *   reconstruct -> index.reconstruct(i)                          pipeline.py:503
+ *   save/load -> faiss.write_index / read_index                  vector_database.py:203,230
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct radad_knn_s* radad_knn_t;
+
+/* dim must be a positive multiple of 4.  id_base is added to every returned index (row-shard offset;
+ * 0 for an unsharded store).  Rows are stored as fp32 in HBM in insertion order. */
+int radad_knn_create(int dim, int metric, int device, int64_t id_base, radad_knn_t* out);
+int radad_knn_destroy(radad_knn_t h);
+int radad_knn_dim(radad_knn_t h, int* dim);
+int radad_knn_metric(radad_knn_t h, int* metric);
+int radad_knn_ntotal(radad_knn_t h, int64_t* n);
+/* reserve HBM for `capacity` rows up front (optional; add grows geometrically otherwise) */
+int radad_knn_reserve(radad_knn_t h, int64_t capacity);
+/* append n rows [n, dim] fp32 (device pointer).  Cosine: rows are normalised on the way in, so
+ * reconstruct returns the normalised row exactly as faiss would return what was added. */
+int radad_knn_add(radad_knn_t h, const float* rows_dev, int64_t n, void* stream);
+/* same, from a host buffer (what index.add(np.ndarray) does); synchronous */
+int radad_knn_add_host(radad_knn_t h, const float* rows_host, int64_t n);
+/* top-k of every query against the whole store.
+ *   q_dev        [nq, dim] fp32
+ *   out_dist_dev [nq, k] fp32  L2: squared distances ascending; IP/cosine: inner products descending
+ *   out_idx_dev  [nq, k] int64 id_base + row; ties are broken towards the LOWER index, always
+ *   slots beyond ntotal are filled with index -1 and distance +inf (L2) / -inf (IP), as faiss does.
+ * k must be in [1, RADAD_KNN_MAX_K]. */
+#define RADAD_KNN_MAX_K 1024
+int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev,
+                     int64_t* out_idx_dev, void* stream);
+/* host-buffer variant (what index.search(np.ndarray, k) does); synchronous */
+int radad_knn_search_host(radad_knn_t h, const float* q_host, int64_t nq, int k, float* out_dist_host,
+                          int64_t* out_idx_host);
+/* batched index.reconstruct: out[i,:] = row (idx[i] - id_base); idx < 0 or out of range -> zeros
+ * (the zero padding pipeline.py:511-512 applies) */
+int radad_knn_reconstruct(radad_knn_t h, const int64_t* idx_dev, int64_t n, float* out_dev, void* stream);
+int radad_knn_reconstruct_host(radad_knn_t h, const int64_t* idx_host, int64_t n, float* out_host);
+/* binary snapshot of the store (header + fp32 rows); load replaces the contents of h */
+int radad_knn_save(radad_knn_t h, const char* path);
+int radad_knn_load(radad_knn_t h, const char* path);
+/* seconds spent in the most recent search's kernels are NOT measured here; use HIP events on `stream`.
+ * Query the launch geometry of the last search (for roofline accounting in bench.py). */
+int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, int* block_threads);
+
+/* merge P partial top-k lists per query into one (used for the multi-GPU all-gather merge and
+ * internally by search):  in_dist/in_idx are [P, nq, k]; metric decides the order; (dist, idx)
+ * lexicographic, idx -1 entries sort last. */
+int radad_topk_merge(int metric, const float* in_dist_dev, const int64_t* in_idx_dev, int n_parts, int64_t nq,
+                     int k, float* out_dist_dev, int64_t* out_idx_dev, int device, void* stream);
+
+/* row L2 normalisation x / (|x| + 1e-12)  (vector_database.py:100-105); in-place allowed */
+int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int device, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding: segment -> front-end -> frame projection -> temporal pyramid pooling -> segment mean.
+ *   segment plan          segmenter.py:8-39 (n_seg = max(1,(N-L)//hop+1); zero pad only when N < L)
+ *   zero-mean/unit-var    feature_extractor.py:25-30 (HF Wav2Vec2FeatureExtractor, eps 1e-7)
+ *   log-mel               feature_extractor.py:94-97 (HF WhisperFeatureExtractor: hann 400 / hop 160,
+ *                         |X|^2, drop last frame, slaney mel 201->80, log10 clamp 1e-10, max-8, (x+4)/4)
+ *   frame projection      stands where the pretrained encoder forward sits (feature_extractor.py:33,110,167)
+ *   pooling               pooling.py:66-103 (adaptive max/avg bins, bin-major layout, levels concatenated)
+ *   segment mean          pipeline.py:411
+ * ---------------------------------------------------------------------------------------------- */
+#define RADAD_MAX_LEVELS 8
+typedef struct radad_embed_cfg {
+    int32_t segment_length;    /* samples per segment (config.segment_length*sample_rate = 32000)   */
+    int32_t hop_length;        /* int(segment_length*(1-overlap)) = 16000                            */
+    int32_t normalize;         /* 1: per-segment zero-mean/unit-variance before the spectrogram      */
+    int32_t n_fft;             /* must be 400                                                        */
+    int32_t fft_hop;           /* must be 160                                                        */
+    int32_t n_mels;            /* must be 80                                                         */
+    int32_t padded_samples;    /* 0: spectrogram of the segment itself (segment_length/160 frames);
+                                  otherwise zero-pad to this many samples first (HF pads to 480000)  */
+    int32_t feat_dim;          /* F, multiple of 32                                                  */
+    int32_t n_levels;          /* pyramid levels (config.tpp_levels)                                 */
+    int32_t levels[RADAD_MAX_LEVELS];
+    int32_t pool_mode;         /* RADAD_POOL_MAX / RADAD_POOL_AVG                                    */
+} radad_embed_cfg;
+
+typedef struct radad_embed_s* radad_embed_t;
+
+/* mel_filters_host [201, 80] fp32 (bins x mels); proj_w_host [80, F] fp32; proj_b_host [F] fp32 */
+int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host, const float* proj_w_host,
+                       const float* proj_b_host, int device, radad_embed_t* out);
+int radad_embed_destroy(radad_embed_t h);
+int radad_embed_output_dim(radad_embed_t h, int* dim);     /* sum(levels)*F  (pooling.py:119-122)    */
+int radad_embed_num_frames(radad_embed_t h, int* frames);   /* frames per segment                      */
+/* number of segments the plan yields for a clip of n samples (segmenter.py:25) */
+int64_t radad_segment_count(int64_t n_samples, int32_t segment_length, int32_t hop_length);
+/* clip embeddings for a batch: clip b is wave_dev[clip_offsets_host[b] .. clip_offsets_host[b+1]).
+ * out_dev [n_clips, output_dim] fp32.  (process_audio_batch, pipeline.py:392-414, minus file loading) */
+int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_host, int64_t n_clips,
+                        float* out_dev, void* stream);
+
+/* stage entry points, for parity with the reference's per-stage functions ------------------------ */
+/* zero-mean/unit-var of S segments: seg s = wave_dev[seg_start_host[s] .. +seg_valid_host[s]) zero
+ * padded to segment_length; out_dev [S, segment_length] */
+int radad_embed_normalize(radad_embed_t h, const float* wave_dev, const int64_t* seg_start_host,
+                          const int32_t* seg_valid_host, int64_t n_seg, float* out_dev, void* stream);
+/* log-mel of S segments -> out_dev [S, frames, 80] (frame-major; HF returns [80, frames]) */
+int radad_embed_logmel(radad_embed_t h, const float* wave_dev, const int64_t* seg_start_host,
+                       const int32_t* seg_valid_host, int64_t n_seg, float* out_dev, void* stream);
+/* frame features of S segments -> out_dev [S, frames, F]  (extract_features protocol) */
+int radad_embed_frame_features(radad_embed_t h, const float* wave_dev, const int64_t* seg_start_host,
+                               const int32_t* seg_valid_host, int64_t n_seg, float* out_dev, void* stream);
+
+/* stand-alone temporal pyramid pooling of one or more [T_i, F] feature blocks stored back to back:
+ * item i = feats_dev[row_offsets_host[i]*F .. row_offsets_host[i+1]*F); out_dev [n_items, sum(levels)*F]
+ * (TemporalPyramidPooling.pool_features / pool_features_batch, pooling.py:88-117) */
+int radad_tpp_forward(const float* feats_dev, const int64_t* row_offsets_host, int64_t n_items, int feat_dim,
+                      const int32_t* levels, int n_levels, int pool_mode, float* out_dev, int device,
+                      void* stream);
+/* mean over groups of rows: out[g,:] = mean(in[group_offsets[g]..group_offsets[g+1], :])  (pipeline.py:411) */
+int radad_group_mean(const float* in_dev, const int64_t* group_offsets_host, int64_t n_groups, int dim,
+                     float* out_dev, int device, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * ProjectionLayer inference forward (projection.py:68-106), fused:
+ *   s = W2 tanh(W1 x + b1) + b2; a = softmax_K(s); c = W4 relu(W3 x + b3) + b4; u = sum_K a c;
+ *   out = W6 LN(W5 u + b5; eps 1e-6) + b6
+ * Weights are given in torch nn.Linear layout ([out, in] row-major), device pointers.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct radad_proj_weights {
+    const float *w1, *b1;       /* attention_score   [H, D], [H]   */
+    const float *w2, *b2;       /* attention_final   [1, H], [1]   */
+    const float *w3, *b3;       /* cst_hidden        [H, D], [H]   */
+    const float *w4, *b4;       /* cst_output        [D, H], [D]   */
+    const float *w5, *b5;       /* weight_sum        [H, D], [H]   */
+    const float *ln_g, *ln_b;   /* normalization     [H], [H]      */
+    const float *w6, *b6;       /* unified_embedding [O, H], [O]   */
+} radad_proj_weights;
+int radad_projection_forward(const radad_proj_weights* w, const float* x_dev /*[B,K,D]*/, int64_t batch, int k,
+                             int dim, int hidden, int out_dim, float* out_dev /*[B,O]*/, float* workspace_dev,
+                             int64_t workspace_bytes, int device, void* stream);
+int64_t radad_projection_workspace_bytes(int64_t batch, int k, int dim, int hidden, int out_dim);
+
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic inputs (bench / tests only): a stateless integer hash so host and device produce the
+ * SAME bits for element (seed, row, col).  See oracle/synth.py for the host twin.
+ * ---------------------------------------------------------------------------------------------- */
+int radad_synth_rows(float* out_dev, int64_t row0, int64_t n_rows, int dim, uint64_t seed, int device, void* stream);
+int radad_synth_audio(float* out_dev, int64_t clip0, int64_t n_clips, int64_t samples_per_clip, uint64_t seed,
+                      int device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADAD_HIP_H */

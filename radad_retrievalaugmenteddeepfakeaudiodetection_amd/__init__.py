@@ -1,0 +1,19 @@
+"""MI355X-native implementation of RADAD's segment -> embed -> retrieve hot path.
+
+Host-side mirror of the reference's call surface (AudioSegmenter, the extractor protocol,
+TemporalPyramidPooling, VectorDatabase(.index), ProjectionLayer, and the two hot pipeline methods) over the
+C ABI of libradad_hip.so (include/radad_hip.h, csrc/*.hip).  There is no CPU fallback: without the
+shared library (or without a ROCm device) the operators raise.
+"""
+from .config import Config
+from .segmenter import AudioSegmenter
+from .pooling import TemporalPyramidPooling
+from .vector_database import HipFlatIndex, VectorDatabase
+from .feature_extractor import MelProjectionFeatureExtractor, build_feature_extractor
+from .pipeline import HotPathPipeline
+from .projection import ProjectionLayer
+from .sharded import ShardedSearch, shard_bounds
+
+__all__ = ["Config", "AudioSegmenter", "TemporalPyramidPooling", "HipFlatIndex", "VectorDatabase",
+           "MelProjectionFeatureExtractor", "build_feature_extractor", "HotPathPipeline", "ProjectionLayer",
+           "ShardedSearch", "shard_bounds"]

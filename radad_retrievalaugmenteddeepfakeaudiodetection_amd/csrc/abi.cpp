@@ -1,0 +1,29 @@
+// abi.cpp -- error text, version and device probes of libradad_hip.so.
+#include "common.h"
+
+#include <string>
+
+static thread_local std::string g_err;
+
+void radad_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" {
+int radad_abi_version(void) { return RADAD_ABI_VERSION; }
+const char* radad_last_error(void) { return g_err.c_str(); }
+int radad_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        radad_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return RADAD_EHIP;
+    }
+    return n;
+}
+}

@@ -1,0 +1,821 @@
+// embed.hip -- segment -> log-mel -> frame projection -> temporal pyramid pooling -> segment mean (gfx950).
+//
+// Replaces, for a whole batch and without leaving the GPU, the four nested Python loops of
+// process_audio_batch (pipeline.py:392-414):
+//   segmenter.py:25-39            -> the (clip, segment) -> sample-range plan built in build_plan()
+//   feature_extractor.py:25-30    -> per-segment zero-mean / unit-variance       (k_logmel prologue)
+//   feature_extractor.py:94-97    -> HF Whisper log-mel (hann 400 / hop 160 / 80 mels) (k_logmel)
+//   feature_extractor.py:33 etc.  -> the encoder stage: a dense frame projection [T,80]x[80,F] (k_proj_pool)
+//   pooling.py:66-103             -> adaptive max/avg pyramid bins               (k_proj_pool epilogue)
+//   pipeline.py:411               -> mean over the clip's segments               (k_proj_pool epilogue)
+//
+// k_logmel  : one workgroup (7 waves) per segment.  The segment (normalised, reflect-padded) lives in LDS.
+//             The 400-point real DFT is folded on the symmetric hann window into two 200-deep
+//             contractions  Re = C . (x[n]+x[400-n]),  Im = S . (x[n]-x[400-n])  and run on
+//             v_mfma_f32_32x32x2_f32 with the (windowed) basis as the A operand, so a lane owns one
+//             frame and its 16 registers are 16 frequency bins; |X|^2 is then fed straight back as the
+//             B operand of a second MFMA against the mel filter bank (no LDS round trip).
+// k_proj_pool: one workgroup (8 waves) per (clip, 256 features).  W fragments stay in registers;
+//             log-mel frames are staged through LDS (clamp max-8 and (x+4)/4 applied on the way in);
+//             the 32-frame x 32-feature accumulators are pooled into the pyramid bins, then the
+//             segment vectors are averaged.
+#include "common.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <vector>
+
+namespace {
+
+constexpr int N_FFT = 400;
+constexpr int FFT_HOP = 160;
+constexpr int N_BINS = 201;
+constexpr int N_MELS = 80;
+constexpr int LM_WAVES = 7;             // 7 frame tiles of 32 cover up to 224 frames
+constexpr int LM_THREADS = LM_WAVES * 64;
+constexpr int NBT = 7;                  // bin tiles of 32 (224 >= 201)
+constexpr int NKK = 25;                 // K = 200 folded taps = 25 groups of 8
+constexpr int KCH = 5;                  // kk groups per staged basis chunk
+constexpr int NCH = NKK / KCH;
+constexpr int NMT = 3;                  // mel tiles of 32 (96 >= 80)
+constexpr int CHUNK_FLOATS = KCH * 2 * 64 * 4;   // 2560 floats = 10 KB
+constexpr int MAX_SEG_LEN = 32000;
+constexpr int SIG_FLOATS = 32800;       // (160*201+400) * 161/160 rounded up
+constexpr int MAX_BINS_TOTAL = 32;      // sum(levels)
+
+__device__ __forceinline__ int sig_pos(int c) { return c + c / FFT_HOP; }   // +1 float per 160: bank-conflict-free frame stride
+
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+
+// block-wide sum over LM_THREADS threads (scratch: >= 8 floats); result broadcast to all threads
+__device__ __forceinline__ float block_sum(float v, float* scratch, int nwaves) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int w = 0; w < nwaves; ++w) t += scratch[w];
+    return t;
+}
+
+struct LogmelParams {
+    const float* wave;           // all clips, back to back
+    const int64_t* seg_start;    // [S] absolute sample offset of each segment
+    const int* seg_valid;        // [S] real samples in the segment (rest zero padded to seg_len)
+    int seg_len;                 // L
+    int normalize;
+    int padded;                  // P: virtual length after zero padding (== L in self mode)
+    int nf;                      // frames actually computed per segment (<= 224)
+    const float* basis;          // [NBT][NKK][2][64][4]
+    const float* fbfrag;         // [NBT][NMT][16][64]
+    unsigned nzmask;             // bit (bt*NMT+mt): that (bin tile, mel tile) block of the filter bank is non-zero
+    float* logmel;               // [S][nf][80] log10(max(mel,1e-10))  (before the max-8 clamp)
+    float* seg_max;              // [S] max over the segment (pre-initialised)
+    float* norm_out;             // optional [S][L]: the normalised segment (stage parity); nullptr otherwise
+};
+
+__global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sig = reinterpret_cast<float*>(smem);                 // [SIG_FLOATS]
+    float* sbas = sig + SIG_FLOATS;                              // [2][CHUNK_FLOATS]
+    float* scratch = sbas + 2 * CHUNK_FLOATS;                    // [16]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int s = blockIdx.x;
+    const int L = p.seg_len;
+    const float* src = p.wave + p.seg_start[s];
+    const int valid = p.seg_valid[s];
+
+    // ---- stage the segment: raw -> stats -> normalise in place -> reflect borders ---------------------
+    float lsum = 0.f;
+    for (int i = tid; i < L; i += LM_THREADS) {
+        const float v = i < valid ? src[i] : 0.f;
+        sig[sig_pos(i + 200)] = v;
+        lsum += v;
+    }
+    float mean = 0.f, sd = 1.f;
+    if (p.normalize) {
+        mean = block_sum(lsum, scratch, LM_WAVES) / (float)L;
+        float lsq = 0.f;
+        for (int i = tid; i < L; i += LM_THREADS) {
+            const float d = sig[sig_pos(i + 200)] - mean;
+            lsq += d * d;
+        }
+        const float var = block_sum(lsq, scratch, LM_WAVES) / (float)L;
+        sd = sqrtf(var + 1e-7f);
+        for (int i = tid; i < L; i += LM_THREADS) {
+            const int ps = sig_pos(i + 200);
+            const float v = (sig[ps] - mean) / sd;
+            sig[ps] = v;
+            if (p.norm_out) p.norm_out[(int64_t)s * L + i] = v;
+        }
+    } else if (p.norm_out) {
+        for (int i = tid; i < L; i += LM_THREADS) p.norm_out[(int64_t)s * L + i] = i < valid ? src[i] : 0.f;
+    }
+    __syncthreads();
+    const int CL = FFT_HOP * (p.nf - 1) + N_FFT + 1;   // chunk samples touched: c in [0, CL)
+    // left border: u = c-200 < 0 reflects to i = 200-c  (c in [0,200))
+    for (int c = tid; c < 200; c += LM_THREADS) sig[sig_pos(c)] = sig[sig_pos(400 - c)];
+    // right border: u >= L.  Self mode (P == L): reflect i = 2(L-1)-u.  Padded mode: zeros (the reflection
+    // at u >= P is never reached by a computed frame).
+    for (int c = L + 200 + tid; c < CL; c += LM_THREADS) {
+        const int u = c - 200;
+        float v = 0.f;
+        if (p.padded == L) {
+            const int i = 2 * (L - 1) - u;
+            v = sig[sig_pos(i + 200)];
+        }
+        sig[sig_pos(c)] = v;
+    }
+    // first basis chunk
+    for (int i = tid; i < CHUNK_FLOATS / 4; i += LM_THREADS)
+        reinterpret_cast<f32x4*>(sbas)[i] = reinterpret_cast<const f32x4*>(p.basis)[i];
+    __syncthreads();
+
+    const int t = min(wave * 32 + l31, p.nf - 1);      // this lane's frame (clamped: extra lanes recompute the last one)
+    const int tbase = FFT_HOP * t;
+    f32x16 zacc[NMT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zacc[m][r] = 0.f;
+
+    int step = 0;   // global chunk counter (bt*NCH + ch)
+    for (int bt = 0; bt < NBT; ++bt) {
+        f32x16 re, im;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { re[r] = 0.f; im[r] = 0.f; }
+        for (int ch = 0; ch < NCH; ++ch, ++step) {
+            const int buf = step & 1;
+            // prefetch the next chunk (global -> registers) while this one is consumed
+            f32x4 pre[2];
+            const bool more = step + 1 < NBT * NCH;
+            const f32x4* nsrc = reinterpret_cast<const f32x4*>(p.basis) + (int64_t)(step + 1) * (CHUNK_FLOATS / 4);
+            if (more) {
+                pre[0] = nsrc[tid];
+                if (tid + LM_THREADS < CHUNK_FLOATS / 4) pre[1] = nsrc[tid + LM_THREADS];
+            }
+            const float* cb = sbas + buf * CHUNK_FLOATS;
+#pragma unroll
+            for (int kq = 0; kq < KCH; ++kq) {
+                const f32x4 bc = *reinterpret_cast<const f32x4*>(cb + (kq * 2 + 0) * 256 + lane * 4);
+                const f32x4 bs = *reinterpret_cast<const f32x4*>(cb + (kq * 2 + 1) * 256 + lane * 4);
+                const int n0 = 8 * (ch * KCH + kq) + 4 * lh + 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + j;
+                    const float x1 = sig[sig_pos(tbase + n)];
+                    const float x2 = sig[sig_pos(tbase + N_FFT - n)];
+                    re = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[j], x1 + x2, re, 0, 0, 0);
+                    im = __builtin_amdgcn_mfma_f32_32x32x2f32(bs[j], x1 - x2, im, 0, 0, 0);
+                }
+            }
+            if (more) {
+                f32x4* dst = reinterpret_cast<f32x4*>(sbas + (buf ^ 1) * CHUNK_FLOATS);
+                dst[tid] = pre[0];
+                if (tid + LM_THREADS < CHUNK_FLOATS / 4) dst[tid + LM_THREADS] = pre[1];
+            }
+            __syncthreads();
+        }
+        // |X|^2 for 16 bins of this lane's frame, then mel += fb^T . pow on the matrix core
+        f32x16 pw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pw[r] = re[r] * re[r] + im[r] * im[r];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+            if ((p.nzmask >> (bt * NMT + mt)) & 1u) {
+                const float* fb = p.fbfrag + ((bt * NMT + mt) * 16) * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    zacc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[r * 64], pw[r], zacc[mt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- log10, segment max, store [frame][mel] --------------------------------------------------------
+    const bool fvalid = wave * 32 + l31 < p.nf;
+    float lmax = -INFINITY;
+    float* orow = p.logmel + ((int64_t)s * p.nf + t) * N_MELS;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int m0 = 32 * mt + 8 * g + 4 * lh;       // registers 4g..4g+3 = mels m0..m0+3
+            if (m0 < N_MELS) {
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = log10f(fmaxf(zacc[mt][4 * g + i], 1e-10f));
+                    lmax = fmaxf(lmax, v[i]);
+                }
+                if (fvalid) *reinterpret_cast<f32x4*>(orow + m0) = v;
+            }
+        }
+    if (!fvalid) lmax = -INFINITY;
+    lmax = wave_max(lmax);
+    if (lane == 0 && lmax > -INFINITY) atomic_max_float(p.seg_max + s, lmax);
+}
+
+// ---- projection + pooling -----------------------------------------------------------------------------
+constexpr int PP_WAVES = 8;            // 8 waves x 32 features = 256 features per workgroup
+constexpr int PP_THREADS = PP_WAVES * 64;
+constexpr int PP_FEATS = PP_WAVES * 32;
+constexpr int PP_FB = 224;           // frames staged per block pass (7 tiles)
+constexpr int PP_LD = N_MELS + 4;    // padded log-mel row in LDS (84 floats: conflict-free b128 frame reads)
+
+struct ProjPoolParams {
+    const float* logmel;        // [S][nf][80]
+    const float* seg_max;       // [S]
+    const int64_t* clip_seg;    // [B+1] segment range of each clip
+    int nf;                     // frames stored per segment
+    int T;                      // frames per segment seen by the pooling (>= nf; frames >= nf are silence)
+    int F;
+    const float* wfrag;         // [F/32][10][64][4]
+    const float* bias;          // [F]
+    int n_levels;
+    int levels[RADAD_MAX_LEVELS];
+    int pool_mode;
+    float* out;                 // [B][nbins*F]      (pooled + segment mean)
+    float* frames_out;          // optional [S][T][F]: per-frame features (extract_features protocol); no pooling
+};
+
+template <bool FRAMES_OUT>
+__global__ __launch_bounds__(PP_THREADS, 2) void k_proj_pool(ProjPoolParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* slm = reinterpret_cast<float*>(smem);             // [PP_FB][PP_LD]
+    float* spool = slm + PP_FB * PP_LD;                      // [nbins][PP_FEATS]  current segment
+    float* sclip = spool + MAX_BINS_TOTAL * PP_FEATS;        // [nbins][PP_FEATS]  running sum over segments
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int clip = blockIdx.x;
+    const int fblk = blockIdx.y;                             // 256-feature block
+    const bool active = (fblk * PP_WAVES + wave) * 32 < p.F; // waves past F only keep the barriers company
+    const int ft = active ? fblk * PP_WAVES + wave : 0;      // this wave's 32-feature tile
+    const int feat = ft * 32 + l31;
+    const int fl = wave * 32 + l31;                          // feature column inside the block
+
+    int nbins = 0;
+    for (int l = 0; l < p.n_levels; ++l) nbins += p.levels[l];
+
+    // W fragments: lane holds W[8kk + 4lh + j][feat], kk = 0..9 (K = 80)
+    f32x4 wf[10];
+#pragma unroll
+    for (int kk = 0; kk < 10; ++kk)
+        wf[kk] = *reinterpret_cast<const f32x4*>(p.wfrag + (((int64_t)ft * 10 + kk) * 64 + lane) * 4);
+    const float bias = p.bias[feat];
+
+    if (!FRAMES_OUT)
+        for (int i = tid; i < nbins * PP_FEATS; i += PP_THREADS) sclip[i] = 0.f;
+
+    const int64_t s_begin = p.clip_seg[clip], s_end = p.clip_seg[clip + 1];
+    for (int64_t s = s_begin; s < s_end; ++s) {
+        const float smax = p.seg_max[s];
+        const float floor_v = smax - 8.0f;
+        if (!FRAMES_OUT) {
+            const float init = p.pool_mode == RADAD_POOL_MAX ? -INFINITY : 0.f;
+            for (int i = tid; i < nbins * PP_FEATS; i += PP_THREADS) spool[i] = init;
+        }
+        for (int f0 = 0; f0 < p.T; f0 += PP_FB) {
+            const int fcount = min(PP_FB, p.T - f0);
+            __syncthreads();   // previous pass finished reading slm
+            // stage frames f0..f0+fcount: clamp to max-8, (x+4)/4   (feature_extraction_whisper.py:161-162)
+            for (int i = tid; i < PP_FB * (N_MELS / 4); i += PP_THREADS) {
+                const int fr = i / (N_MELS / 4), c4 = i % (N_MELS / 4);
+                f32x4 v = {-10.f, -10.f, -10.f, -10.f};       // log10(1e-10): a frame of pure zero padding
+                const int tt = f0 + fr;
+                if (fr < fcount && tt < p.nf)
+                    v = *reinterpret_cast<const f32x4*>(p.logmel + ((int64_t)s * p.nf + tt) * N_MELS + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (fmaxf(v[e], floor_v) + 4.0f) / 4.0f;
+                *reinterpret_cast<f32x4*>(slm + fr * PP_LD + c4 * 4) = v;
+            }
+            __syncthreads();
+            const int ntile = (fcount + 31) / 32;
+            for (int tile = 0; tile < ntile; ++tile) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                const float* arow = slm + (tile * 32 + l31) * PP_LD + 4 * lh;
+#pragma unroll
+                for (int kk = 0; kk < 10; ++kk) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(arow + kk * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wf[kk][j], acc, 0, 0, 0);
+                }
+                // acc[r] = feature `feat` of frame tfirst + (r&3) + 8(r>>2) + 4lh
+                const int tfirst = f0 + tile * 32;
+                if (!active) continue;
+                if (FRAMES_OUT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int tt = tfirst + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (tt < p.T) p.frames_out[((int64_t)s * p.T + tt) * p.F + feat] = acc[r] + bias;
+                    }
+                } else {
+                    const int tlast = min(tfirst + 32, p.T);   // exclusive
+                    int b = 0;
+                    for (int l = 0; l < p.n_levels; ++l) {
+                        const int lv = p.levels[l];
+                        for (int i = 0; i < lv; ++i, ++b) {
+                            const int lo = (int)(((int64_t)i * p.T) / lv);
+                            const int hi = (int)(((int64_t)(i + 1) * p.T + lv - 1) / lv);
+                            if (hi <= tfirst || lo >= tlast) continue;        // wave-uniform
+                            float v = p.pool_mode == RADAD_POOL_MAX ? -INFINITY : 0.f;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int tt = tfirst + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                const bool in = tt >= lo && tt < hi;       // hi <= T
+                                const float x = acc[r] + bias;
+                                if (p.pool_mode == RADAD_POOL_MAX) v = in ? fmaxf(v, x) : v;
+                                else v += in ? x : 0.f;
+                            }
+                            const float o = __shfl_xor(v, 32, 64);
+                            if (lh == 0) {
+                                float* dst = spool + b * PP_FEATS + fl;
+                                if (p.pool_mode == RADAD_POOL_MAX) *dst = fmaxf(*dst, fmaxf(v, o));
+                                else *dst += v + o;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!FRAMES_OUT) {
+            // segment vector -> running clip sum (each wave only touches its own 32 columns)
+            if (lh == 0 && active) {
+                int b = 0;
+                for (int l = 0; l < p.n_levels; ++l) {
+                    const int lv = p.levels[l];
+                    for (int i = 0; i < lv; ++i, ++b) {
+                        float v = spool[b * PP_FEATS + fl];
+                        if (p.pool_mode == RADAD_POOL_AVG) {
+                            const int lo = (int)(((int64_t)i * p.T) / lv);
+                            const int hi = (int)(((int64_t)(i + 1) * p.T + lv - 1) / lv);
+                            v = v / (float)(hi - lo);
+                        }
+                        sclip[b * PP_FEATS + fl] += v;
+                    }
+                }
+            }
+        }
+    }
+    if (!FRAMES_OUT && lh == 0 && active) {
+        const float nseg = (float)(s_end - s_begin);
+        for (int b = 0; b < nbins; ++b)
+            p.out[(int64_t)clip * nbins * p.F + (int64_t)b * p.F + feat] = sclip[b * PP_FEATS + fl] / nseg;
+    }
+}
+
+// finalise log-mel for the stage API: out[s][t][m] = (max(x, smax-8)+4)/4, frames >= nf are silence
+__global__ void k_logmel_finalize(const float* __restrict__ logmel, const float* __restrict__ seg_max, int nf, int T,
+                                  int64_t n_seg, float* __restrict__ out) {
+    const int64_t total = n_seg * T * N_MELS;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % N_MELS);
+        const int64_t st = i / N_MELS;
+        const int t = (int)(st % T);
+        const int64_t s = st / T;
+        const float x = t < nf ? logmel[(s * nf + t) * N_MELS + m] : -10.f;
+        out[i] = (fmaxf(x, seg_max[s] - 8.0f) + 4.0f) / 4.0f;
+    }
+}
+
+__global__ void k_fill(float* p, float v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// ---- stand-alone temporal pyramid pooling (pool_features / pool_features_batch) --------------------------
+// grid (items, ceil(F/256)); thread = one feature column; walks the T rows once per bin
+__global__ __launch_bounds__(256) void k_tpp(const float* __restrict__ feats, const int64_t* __restrict__ row_off, int F,
+                                             int n_levels, const int* __restrict__ levels_dev, int pool_mode, int nbins,
+                                             float* __restrict__ out) {
+    const int item = blockIdx.x;
+    const int f = blockIdx.y * 256 + threadIdx.x;
+    if (f >= F) return;
+    const int64_t r0 = row_off[item];
+    const int T = (int)(row_off[item + 1] - r0);
+    const float* base = feats + r0 * F + f;
+    int b = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const int lv = levels_dev[l];
+        for (int i = 0; i < lv; ++i, ++b) {
+            const int lo = (int)(((int64_t)i * T) / lv);
+            const int hi = (int)(((int64_t)(i + 1) * T + lv - 1) / lv);
+            float v;
+            if (pool_mode == RADAD_POOL_MAX) {
+                v = -INFINITY;
+                for (int t = lo; t < hi; ++t) v = fmaxf(v, base[(int64_t)t * F]);
+            } else {
+                v = 0.f;
+                for (int t = lo; t < hi; ++t) v += base[(int64_t)t * F];
+                v = v / (float)(hi - lo);
+            }
+            out[((int64_t)item * nbins + b) * F + f] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_group_mean(const float* __restrict__ in, const int64_t* __restrict__ goff, int dim,
+                                                    float* __restrict__ out) {
+    const int g = blockIdx.x;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= dim) return;
+    const int64_t a = goff[g], b = goff[g + 1];
+    float v = 0.f;
+    for (int64_t r = a; r < b; ++r) v += in[r * dim + c];
+    out[(int64_t)g * dim + c] = v / (float)(b - a);
+}
+
+constexpr size_t logmel_lds_bytes() { return sizeof(float) * (SIG_FLOATS + 2 * CHUNK_FLOATS + 16); }
+constexpr size_t projpool_lds_bytes() { return sizeof(float) * (PP_FB * PP_LD + 2 * MAX_BINS_TOTAL * PP_FEATS); }
+
+// growable device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return RADAD_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t cap = need + need / 4;
+        if (hipMalloc(&p, cap) != hipSuccess) { radad_set_error("hipMalloc of %zu bytes failed", cap); return RADAD_ENOMEM; }
+        bytes = cap;
+        return RADAD_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct radad_embed_s {
+    radad_embed_cfg cfg;
+    int device = 0;
+    int nbins = 0, T = 0, nf = 0, padded = 0;
+    unsigned nzmask = 0;
+    float *basis = nullptr, *fbfrag = nullptr, *wfrag = nullptr, *bias = nullptr;
+    int* levels_dev = nullptr;
+    // plan cache + scratch
+    std::vector<int64_t> plan_key;       // the clip_offsets the cached plan was built from
+    int64_t plan_nseg = 0;
+    DevBuf seg_start, seg_valid, clip_seg, logmel, seg_max, misc;
+    std::mutex mu;
+};
+
+extern "C" int64_t radad_segment_count(int64_t n_samples, int32_t segment_length, int32_t hop_length) {
+    if (segment_length <= 0 || hop_length <= 0 || n_samples < 0) return -1;
+    // Python floor division (segmenter.py:25): (N-L)//hop is negative for N < L, max(1, .) then yields 1
+    const int64_t d = n_samples - segment_length;
+    int64_t q = d / hop_length;
+    if ((d % hop_length != 0) && (d < 0)) --q;
+    return std::max<int64_t>(1, q + 1);
+}
+
+static int upload(DevBuf& b, const void* host, size_t bytes, hipStream_t st) {
+    int rc = b.ensure(bytes ? bytes : 1);
+    if (rc) return rc;
+    if (bytes) RADAD_HIP_CHECK(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, st));
+    return RADAD_OK;
+}
+
+// Build the (clip, segment) -> sample range plan (segmenter.py:25-39) and upload it.
+static int build_plan(radad_embed_t h, const int64_t* clip_offsets, int64_t n_clips, hipStream_t st) {
+    if ((int64_t)h->plan_key.size() == n_clips + 1 && memcmp(h->plan_key.data(), clip_offsets, sizeof(int64_t) * (n_clips + 1)) == 0)
+        return RADAD_OK;
+    std::vector<int64_t> seg_start, clip_seg(n_clips + 1, 0);
+    std::vector<int32_t> seg_valid;
+    const int L = h->cfg.segment_length, hop = h->cfg.hop_length;
+    for (int64_t b = 0; b < n_clips; ++b) {
+        const int64_t n = clip_offsets[b + 1] - clip_offsets[b];
+        RADAD_REQUIRE(n >= 0, "radad_embed_forward: clip_offsets must be non-decreasing");
+        const int64_t ns = radad_segment_count(n, L, hop);
+        for (int64_t i = 0; i < ns; ++i) {
+            const int64_t start = i * hop;
+            seg_start.push_back(clip_offsets[b] + start);
+            seg_valid.push_back((int32_t)std::max<int64_t>(0, std::min<int64_t>(L, n - start)));
+        }
+        clip_seg[b + 1] = clip_seg[b] + ns;
+    }
+    RADAD_HIP_CHECK(hipStreamSynchronize(st));   // pageable host vectors below go out of scope after the copies
+    int rc;
+    if ((rc = upload(h->seg_start, seg_start.data(), seg_start.size() * sizeof(int64_t), st))) return rc;
+    if ((rc = upload(h->seg_valid, seg_valid.data(), seg_valid.size() * sizeof(int32_t), st))) return rc;
+    if ((rc = upload(h->clip_seg, clip_seg.data(), clip_seg.size() * sizeof(int64_t), st))) return rc;
+    RADAD_HIP_CHECK(hipStreamSynchronize(st));
+    h->plan_key.assign(clip_offsets, clip_offsets + n_clips + 1);
+    h->plan_nseg = (int64_t)seg_start.size();
+    return RADAD_OK;
+}
+
+static int upload_plan_explicit(radad_embed_t h, const int64_t* seg_start, const int32_t* seg_valid, int64_t n_seg, hipStream_t st) {
+    for (int64_t i = 0; i < n_seg; ++i)
+        RADAD_REQUIRE(seg_valid[i] >= 0 && seg_valid[i] <= h->cfg.segment_length && seg_start[i] >= 0,
+                      "segment %lld: bad start/valid", (long long)i);
+    h->plan_key.clear();
+    RADAD_HIP_CHECK(hipStreamSynchronize(st));
+    int rc;
+    if ((rc = upload(h->seg_start, seg_start, n_seg * sizeof(int64_t), st))) return rc;
+    if ((rc = upload(h->seg_valid, seg_valid, n_seg * sizeof(int32_t), st))) return rc;
+    std::vector<int64_t> cs(n_seg + 1);
+    for (int64_t i = 0; i <= n_seg; ++i) cs[i] = i;            // one "clip" per segment
+    if ((rc = upload(h->clip_seg, cs.data(), cs.size() * sizeof(int64_t), st))) return rc;
+    RADAD_HIP_CHECK(hipStreamSynchronize(st));
+    h->plan_nseg = n_seg;
+    return RADAD_OK;
+}
+
+static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, float* norm_out, hipStream_t st) {
+    int rc;
+    if ((rc = h->logmel.ensure((size_t)n_seg * h->nf * N_MELS * sizeof(float)))) return rc;
+    if ((rc = h->seg_max.ensure((size_t)n_seg * sizeof(float)))) return rc;
+    const float init = h->T > h->nf ? -10.f : -INFINITY;   // padded mode: silence frames take part in the max
+    hipLaunchKernelGGL(k_fill, dim3((unsigned)std::min<int64_t>(1024, ceil_div64(n_seg, 256))), dim3(256), 0, st,
+                       (float*)h->seg_max.p, init, n_seg);
+    LogmelParams p;
+    p.wave = wave_dev; p.seg_start = (const int64_t*)h->seg_start.p; p.seg_valid = (const int*)h->seg_valid.p;
+    p.seg_len = h->cfg.segment_length; p.normalize = h->cfg.normalize; p.padded = h->padded; p.nf = h->nf;
+    p.basis = h->basis; p.fbfrag = h->fbfrag; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
+    p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out;
+    hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+static void fill_projpool(radad_embed_t h, ProjPoolParams& p) {
+    p.logmel = (const float*)h->logmel.p; p.seg_max = (const float*)h->seg_max.p; p.clip_seg = (const int64_t*)h->clip_seg.p;
+    p.nf = h->nf; p.T = h->T; p.F = h->cfg.feat_dim; p.wfrag = h->wfrag; p.bias = h->bias; p.n_levels = h->cfg.n_levels;
+    for (int i = 0; i < RADAD_MAX_LEVELS; ++i) p.levels[i] = i < h->cfg.n_levels ? h->cfg.levels[i] : 0;
+    p.pool_mode = h->cfg.pool_mode; p.out = nullptr; p.frames_out = nullptr;
+}
+
+extern "C" {
+
+int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host, const float* proj_w_host,
+                       const float* proj_b_host, int device, radad_embed_t* out) {
+    RADAD_REQUIRE(cfg && mel_filters_host && proj_w_host && proj_b_host && out, "radad_embed_create: NULL argument");
+    RADAD_REQUIRE(cfg->n_fft == N_FFT && cfg->fft_hop == FFT_HOP && cfg->n_mels == N_MELS,
+                  "radad_embed_create: only n_fft=400 / hop=160 / 80 mels (the HF Whisper front-end) is built");
+    RADAD_REQUIRE(cfg->segment_length > 0 && cfg->segment_length <= MAX_SEG_LEN && cfg->segment_length % FFT_HOP == 0 &&
+                      cfg->segment_length >= N_FFT,
+                  "radad_embed_create: segment_length must be a multiple of 160 in [400, %d] (got %d)", MAX_SEG_LEN,
+                  cfg->segment_length);
+    RADAD_REQUIRE(cfg->hop_length > 0, "radad_embed_create: hop_length must be positive");
+    RADAD_REQUIRE(cfg->feat_dim > 0 && cfg->feat_dim % 32 == 0, "radad_embed_create: feat_dim must be a multiple of 32");
+    RADAD_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= RADAD_MAX_LEVELS, "radad_embed_create: 1..%d pyramid levels", RADAD_MAX_LEVELS);
+    RADAD_REQUIRE(cfg->pool_mode == RADAD_POOL_MAX || cfg->pool_mode == RADAD_POOL_AVG, "Unsupported pooling type: %d", cfg->pool_mode);
+    int nbins = 0;
+    for (int i = 0; i < cfg->n_levels; ++i) {
+        RADAD_REQUIRE(cfg->levels[i] >= 1, "radad_embed_create: pyramid level must be >= 1");
+        nbins += cfg->levels[i];
+    }
+    RADAD_REQUIRE(nbins <= MAX_BINS_TOTAL, "radad_embed_create: sum(levels) must be <= %d", MAX_BINS_TOTAL);
+    const int L = cfg->segment_length;
+    const int padded = cfg->padded_samples > 0 ? cfg->padded_samples : L;
+    RADAD_REQUIRE(padded >= L && padded % FFT_HOP == 0, "radad_embed_create: padded_samples must be a multiple of 160 >= segment_length");
+    const int T = padded / FFT_HOP;
+    const int nf_sig = (L + 200 + FFT_HOP - 1) / FFT_HOP;   // frames whose window still touches the segment
+    const int nf = std::min(T, nf_sig);
+    RADAD_REQUIRE(nf <= LM_WAVES * 32, "radad_embed_create: %d frames per segment exceed the %d the kernel covers", nf, LM_WAVES * 32);
+    RADAD_REQUIRE(padded == L || padded >= L + 2 * N_FFT, "radad_embed_create: padded_samples must be 0 or >= segment_length + 800");
+    int ndev = 0;
+    RADAD_HIP_CHECK(hipGetDeviceCount(&ndev));
+    RADAD_REQUIRE(device >= 0 && device < ndev, "radad_embed_create: device %d not in [0,%d)", device, ndev);
+
+    radad_embed_s* h = new (std::nothrow) radad_embed_s();
+    if (!h) { radad_set_error("out of host memory"); return RADAD_ENOMEM; }
+    h->cfg = *cfg; h->device = device; h->nbins = nbins; h->T = T; h->nf = nf; h->padded = padded;
+    DeviceGuard g(device);
+
+    // folded, windowed DFT basis in MFMA fragment order
+    std::vector<float> basis((size_t)NBT * NKK * 2 * 64 * 4);
+    const double PI = 3.14159265358979323846;
+    for (int bt = 0; bt < NBT; ++bt)
+        for (int kk = 0; kk < NKK; ++kk)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int n = 8 * kk + 4 * (lane >> 5) + j + 1;     // 1..200
+                    const int bin = 32 * bt + (lane & 31);
+                    double c = 0.0, s = 0.0;
+                    if (bin < N_BINS) {
+                        const double w = 0.5 - 0.5 * cos(2.0 * PI * n / N_FFT);   // periodic hann
+                        const int ph = (int)(((int64_t)bin * n) % N_FFT);
+                        if (n < 200) { c = w * cos(2.0 * PI * ph / N_FFT); s = w * sin(2.0 * PI * ph / N_FFT); }
+                        else { c = 0.5 * ((bin & 1) ? -1.0 : 1.0); s = 0.0; }      // n = 200 pairs with itself
+                    }
+                    const size_t base = ((((size_t)bt * NKK + kk) * 2) * 64 + lane) * 4 + j;
+                    basis[base] = (float)c;
+                    basis[base + 256] = (float)s;
+                }
+    // mel filter bank in MFMA A-fragment order
+    std::vector<float> fbfrag((size_t)NBT * NMT * 16 * 64, 0.f);
+    unsigned nz = 0;
+    for (int bt = 0; bt < NBT; ++bt)
+        for (int mt = 0; mt < NMT; ++mt)
+            for (int r = 0; r < 16; ++r)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int bin = 32 * bt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int mel = 32 * mt + (lane & 31);
+                    float v = 0.f;
+                    if (bin < N_BINS && mel < N_MELS) v = mel_filters_host[bin * N_MELS + mel];
+                    if (v != 0.f) nz |= 1u << (bt * NMT + mt);
+                    fbfrag[(((size_t)bt * NMT + mt) * 16 + r) * 64 + lane] = v;
+                }
+    h->nzmask = nz;
+    const int F = cfg->feat_dim;
+    std::vector<float> wfrag((size_t)(F / 32) * 10 * 64 * 4);
+    for (int ft = 0; ft < F / 32; ++ft)
+        for (int kk = 0; kk < 10; ++kk)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int kidx = 8 * kk + 4 * (lane >> 5) + j;
+                    wfrag[(((size_t)ft * 10 + kk) * 64 + lane) * 4 + j] = proj_w_host[(size_t)kidx * F + ft * 32 + (lane & 31)];
+                }
+    auto put = [&](float** dst, const void* src, size_t bytes) -> int {
+        if (hipMalloc((void**)dst, bytes) != hipSuccess) { radad_set_error("hipMalloc failed"); return RADAD_ENOMEM; }
+        if (hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { radad_set_error("H2D copy failed"); return RADAD_EHIP; }
+        return RADAD_OK;
+    };
+    int rc = put(&h->basis, basis.data(), basis.size() * sizeof(float));
+    if (!rc) rc = put(&h->fbfrag, fbfrag.data(), fbfrag.size() * sizeof(float));
+    if (!rc) rc = put(&h->wfrag, wfrag.data(), wfrag.size() * sizeof(float));
+    if (!rc) rc = put(&h->bias, proj_b_host, (size_t)F * sizeof(float));
+    if (!rc) rc = put((float**)&h->levels_dev, cfg->levels, sizeof(int32_t) * RADAD_MAX_LEVELS);
+    if (!rc) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)logmel_lds_bytes()) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)projpool_lds_bytes()) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)projpool_lds_bytes()) != hipSuccess) {
+            radad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+            rc = RADAD_EHIP;
+        }
+    }
+    if (rc) { radad_embed_destroy(h); return rc; }
+    *out = h;
+    return RADAD_OK;
+}
+
+int radad_embed_destroy(radad_embed_t h) {
+    if (!h) return RADAD_OK;
+    {
+        DeviceGuard g(h->device);
+        if (h->basis) (void)hipFree(h->basis);
+        if (h->fbfrag) (void)hipFree(h->fbfrag);
+        if (h->wfrag) (void)hipFree(h->wfrag);
+        if (h->bias) (void)hipFree(h->bias);
+        if (h->levels_dev) (void)hipFree(h->levels_dev);
+        h->seg_start.release(); h->seg_valid.release(); h->clip_seg.release(); h->logmel.release(); h->seg_max.release();
+        h->misc.release();
+    }
+    delete h;
+    return RADAD_OK;
+}
+
+int radad_embed_output_dim(radad_embed_t h, int* dim) { RADAD_REQUIRE(h && dim, "NULL argument"); *dim = h->nbins * h->cfg.feat_dim; return RADAD_OK; }
+int radad_embed_num_frames(radad_embed_t h, int* frames) { RADAD_REQUIRE(h && frames, "NULL argument"); *frames = h->T; return RADAD_OK; }
+
+int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_host, int64_t n_clips,
+                        float* out_dev, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    RADAD_REQUIRE(n_clips >= 0, "radad_embed_forward: n_clips < 0");
+    if (n_clips == 0) return RADAD_OK;
+    RADAD_REQUIRE(wave_dev && clip_offsets_host && out_dev, "radad_embed_forward: NULL buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = build_plan(h, clip_offsets_host, n_clips, st);
+    if (rc) return rc;
+    if ((rc = launch_logmel(h, wave_dev, h->plan_nseg, nullptr, st))) return rc;
+    ProjPoolParams p;
+    fill_projpool(h, p);
+    p.out = out_dev;
+    hipLaunchKernelGGL(k_proj_pool<false>, dim3((unsigned)n_clips, (unsigned)((h->cfg.feat_dim + PP_FEATS - 1) / PP_FEATS)), dim3(PP_THREADS),
+                       projpool_lds_bytes(), st, p);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+int radad_embed_normalize(radad_embed_t h, const float* wave_dev, const int64_t* seg_start_host, const int32_t* seg_valid_host,
+                          int64_t n_seg, float* out_dev, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    if (n_seg == 0) return RADAD_OK;
+    RADAD_REQUIRE(wave_dev && seg_start_host && seg_valid_host && out_dev && n_seg > 0, "radad_embed_normalize: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = upload_plan_explicit(h, seg_start_host, seg_valid_host, n_seg, st);
+    if (rc) return rc;
+    return launch_logmel(h, wave_dev, n_seg, out_dev, st);
+}
+
+int radad_embed_logmel(radad_embed_t h, const float* wave_dev, const int64_t* seg_start_host, const int32_t* seg_valid_host,
+                       int64_t n_seg, float* out_dev, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    if (n_seg == 0) return RADAD_OK;
+    RADAD_REQUIRE(wave_dev && seg_start_host && seg_valid_host && out_dev && n_seg > 0, "radad_embed_logmel: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = upload_plan_explicit(h, seg_start_host, seg_valid_host, n_seg, st);
+    if (rc) return rc;
+    if ((rc = launch_logmel(h, wave_dev, n_seg, nullptr, st))) return rc;
+    hipLaunchKernelGGL(k_logmel_finalize, dim3(2048), dim3(256), 0, st, (const float*)h->logmel.p, (const float*)h->seg_max.p, h->nf,
+                       h->T, n_seg, out_dev);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+int radad_embed_frame_features(radad_embed_t h, const float* wave_dev, const int64_t* seg_start_host,
+                               const int32_t* seg_valid_host, int64_t n_seg, float* out_dev, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    if (n_seg == 0) return RADAD_OK;
+    RADAD_REQUIRE(wave_dev && seg_start_host && seg_valid_host && out_dev && n_seg > 0, "radad_embed_frame_features: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = upload_plan_explicit(h, seg_start_host, seg_valid_host, n_seg, st);
+    if (rc) return rc;
+    if ((rc = launch_logmel(h, wave_dev, n_seg, nullptr, st))) return rc;
+    ProjPoolParams p;
+    fill_projpool(h, p);
+    p.frames_out = out_dev;
+    hipLaunchKernelGGL(k_proj_pool<true>, dim3((unsigned)n_seg, (unsigned)((h->cfg.feat_dim + PP_FEATS - 1) / PP_FEATS)), dim3(PP_THREADS),
+                       projpool_lds_bytes(), st, p);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+int radad_tpp_forward(const float* feats_dev, const int64_t* row_offsets_host, int64_t n_items, int feat_dim,
+                      const int32_t* levels, int n_levels, int pool_mode, float* out_dev, int device, void* stream) {
+    RADAD_REQUIRE(n_items >= 0 && feat_dim > 0, "radad_tpp_forward: bad shape");
+    RADAD_REQUIRE(levels && n_levels >= 1 && n_levels <= RADAD_MAX_LEVELS, "radad_tpp_forward: 1..%d levels", RADAD_MAX_LEVELS);
+    RADAD_REQUIRE(pool_mode == RADAD_POOL_MAX || pool_mode == RADAD_POOL_AVG, "Unsupported pooling type: %d", pool_mode);
+    if (n_items == 0) return RADAD_OK;
+    RADAD_REQUIRE(feats_dev && row_offsets_host && out_dev, "radad_tpp_forward: NULL buffer");
+    int nbins = 0;
+    for (int i = 0; i < n_levels; ++i) { RADAD_REQUIRE(levels[i] >= 1, "radad_tpp_forward: level must be >= 1"); nbins += levels[i]; }
+    for (int64_t i = 0; i < n_items; ++i)
+        RADAD_REQUIRE(row_offsets_host[i + 1] > row_offsets_host[i], "radad_tpp_forward: item %lld has no rows", (long long)i);
+    DeviceGuard g(device);
+    hipStream_t st = (hipStream_t)stream;
+    // small per-call upload (offsets + levels); freed after the launch is enqueued and the stream drained
+    const size_t off_bytes = (size_t)(n_items + 1) * sizeof(int64_t);
+    char* tmp = nullptr;
+    if (hipMalloc((void**)&tmp, off_bytes + sizeof(int32_t) * RADAD_MAX_LEVELS) != hipSuccess) { radad_set_error("hipMalloc failed"); return RADAD_ENOMEM; }
+    int rc = RADAD_OK;
+    if (hipMemcpyAsync(tmp, row_offsets_host, off_bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(tmp + off_bytes, levels, sizeof(int32_t) * n_levels, hipMemcpyHostToDevice, st) != hipSuccess) {
+        radad_set_error("H2D copy failed");
+        rc = RADAD_EHIP;
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(k_tpp, dim3((unsigned)n_items, (unsigned)((feat_dim + 255) / 256)), dim3(256), 0, st, feats_dev,
+                           (const int64_t*)tmp, feat_dim, n_levels, (const int*)(tmp + off_bytes), pool_mode, nbins, out_dev);
+        if (hipGetLastError() != hipSuccess) { radad_set_error("k_tpp launch failed"); rc = RADAD_EHIP; }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) { radad_set_error("k_tpp failed"); rc = RADAD_EHIP; }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int radad_group_mean(const float* in_dev, const int64_t* group_offsets_host, int64_t n_groups, int dim, float* out_dev,
+                     int device, void* stream) {
+    RADAD_REQUIRE(n_groups >= 0 && dim > 0, "radad_group_mean: bad shape");
+    if (n_groups == 0) return RADAD_OK;
+    RADAD_REQUIRE(in_dev && group_offsets_host && out_dev, "radad_group_mean: NULL buffer");
+    for (int64_t i = 0; i < n_groups; ++i)
+        RADAD_REQUIRE(group_offsets_host[i + 1] > group_offsets_host[i], "radad_group_mean: group %lld is empty", (long long)i);
+    DeviceGuard g(device);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t off_bytes = (size_t)(n_groups + 1) * sizeof(int64_t);
+    int64_t* tmp = nullptr;
+    if (hipMalloc((void**)&tmp, off_bytes) != hipSuccess) { radad_set_error("hipMalloc failed"); return RADAD_ENOMEM; }
+    int rc = RADAD_OK;
+    if (hipMemcpyAsync(tmp, group_offsets_host, off_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { radad_set_error("H2D copy failed"); rc = RADAD_EHIP; }
+    if (!rc) {
+        hipLaunchKernelGGL(k_group_mean, dim3((unsigned)n_groups, (unsigned)((dim + 255) / 256)), dim3(256), 0, st, in_dev, tmp, dim, out_dev);
+        if (hipGetLastError() != hipSuccess) { radad_set_error("k_group_mean launch failed"); rc = RADAD_EHIP; }
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) { radad_set_error("k_group_mean failed"); rc = RADAD_EHIP; }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,726 @@
+// knn.hip -- HBM-resident vector store + brute-force top-k for gfx950 (MI355X).
+//
+// Replaces the faiss IndexFlatL2 / IndexFlatIP object RADAD keeps in VectorDatabase.index
+// (vector_database.py:56-97 create, :138 add, :181 search; pipeline.py:503 reconstruct).
+//
+// Kernels
+//   k_rows_prepare   : append path -- copy (IP), copy + |y|^2 (L2) or normalise (cosine) incoming rows.
+//   k_knn_f32        : the scan.  S = Y . Q^T on v_mfma_f32_32x32x2_f32 (exact f32) with a fused
+//                      per-workgroup top-k: 128 store rows x 128 queries per tile, K stepped 32 at a
+//                      time through double-buffered LDS; the store rows are the MFMA "A" side so that a
+//                      lane owns ONE query column and its running k-th-best threshold lives in a register.
+//   k_topk_merge     : P-way merge of sorted partial lists by (distance, index), one wave per query.
+//   k_gather_rows    : batched reconstruct.
+//
+// Layout in HBM: rows [capacity, dim] fp32 row-major (insertion order), ynorm [capacity] fp32 (L2 only).
+// Partial results: score [nq, n_splits, k] fp32 + local row index int32, same shape.
+#include "common.h"
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+constexpr int KT_M = 128;       // store rows per tile (MFMA A rows)
+constexpr int KT_N = 128;       // queries per tile (MFMA B columns)
+constexpr int KT_K = 32;        // K step
+constexpr int KT_LD = KT_K + 4; // padded LDS row (floats): 36-dword stride is conflict-free for ds_read_b128
+constexpr int KNN_THREADS = 256;
+constexpr int KS_LD = KT_M + 4;  // score-tile row (floats): 132-dword stride keeps b128 writes and reads conflict-free
+constexpr int IDX_SENTINEL = 0x7fffffff;
+
+struct KnnParams {
+    const float* db;      // [n, dim]
+    const float* ynorm;   // [n] (L2) or nullptr
+    const float* q;       // [nq, dim] (already normalised for cosine)
+    int64_t n;
+    int nq;
+    int dim;
+    int k;
+    int l2;               // 1: score = 2*dot - |y|^2 ; 0: score = dot
+    int n_qtiles;
+    int n_splits;         // multiple of 8
+    int64_t chunk_rows;   // rows per split, multiple of KT_M
+    float* part_score;    // [nq, n_splits, k]
+    int* part_idx;        // [nq, n_splits, k]
+};
+
+__device__ __forceinline__ bool better(float s, int i, float ws, int wi) {
+    return s > ws || (s == ws && i < wi);
+}
+
+__global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32(KnnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sA = reinterpret_cast<float*>(smem);          // [2][KT_M][KT_LD]
+    float* sB = sA + 2 * KT_M * KT_LD;                   // [2][KT_N][KT_LD]
+    float* sS = sA;                                      // [KT_N][KS_LD] score tile, aliases both (epilogue only)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1;    // which 64-row half of the store tile
+    const int wn = wave >> 1;   // which 64-query half
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+
+    // XCD-aware mapping: blocks b and b+8 share an XCD (round-robin dispatch), so the n_qtiles blocks
+    // that stream the SAME store chunk are placed on one XCD and run together -> the chunk is pulled
+    // from HBM once and re-served from that XCD's L2.  Speed only; any placement is correct.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7;
+    const int slot = bid >> 3;
+    const int qt = slot % p.n_qtiles;
+    const int split = (slot / p.n_qtiles) * 8 + xcd;
+
+    const int q0 = qt * KT_N;
+    const int64_t chunk_begin = (int64_t)split * p.chunk_rows;
+    const int64_t chunk_end = min(chunk_begin + p.chunk_rows, p.n);
+    const int nk = (p.dim + KT_K - 1) / KT_K;
+    const int k = p.k;
+
+    // this block's output lists double as the running top-k lists (rarely touched; L2-resident)
+    // thread t < 128 owns query q0+t for the whole scan: its threshold stays in a register.
+    float my_thr = -INFINITY;
+    float* my_ls = nullptr;
+    int* my_li = nullptr;
+    if (tid < KT_N && q0 + tid < p.nq) {
+        my_ls = p.part_score + ((int64_t)(q0 + tid) * p.n_splits + split) * k;
+        my_li = p.part_idx + ((int64_t)(q0 + tid) * p.n_splits + split) * k;
+        for (int j = 0; j < k; ++j) { my_ls[j] = -INFINITY; my_li[j] = IDX_SENTINEL; }
+    }
+    if (chunk_begin >= chunk_end) return;
+
+    // staging registers: 4 float4 of the store tile + 4 float4 of the query tile per thread
+    f32x4 ra[4], rb[4];
+    const int ld_r = tid >> 3;        // + 32*i
+    const int ld_c = (tid & 7) * 4;
+
+    for (int64_t row0 = chunk_begin; row0 < chunk_end; row0 += KT_M) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+        auto gload = [&](int kc) {
+            const int kcol = kc * KT_K + ld_c;
+            const bool kin = kcol < p.dim;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = ld_r + 32 * i;
+                const int64_t row = row0 + r;
+                const int qrow = q0 + r;
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                ra[i] = (kin && row < chunk_end) ? *reinterpret_cast<const f32x4*>(p.db + row * p.dim + kcol) : z;
+                rb[i] = (kin && qrow < p.nq) ? *reinterpret_cast<const f32x4*>(p.q + (int64_t)qrow * p.dim + kcol) : z;
+            }
+        };
+        auto swrite = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = ld_r + 32 * i;
+                *reinterpret_cast<f32x4*>(sA + (buf * KT_M + r) * KT_LD + ld_c) = ra[i];
+                *reinterpret_cast<f32x4*>(sB + (buf * KT_N + r) * KT_LD + ld_c) = rb[i];
+            }
+        };
+
+        gload(0);
+        swrite(0);
+        __syncthreads();
+        for (int kc = 0; kc < nk; ++kc) {
+            const int buf = kc & 1;
+            if (kc + 1 < nk) gload(kc + 1);
+            const float* a_base = sA + (buf * KT_M + wm * 64 + l31) * KT_LD + 4 * lh;
+            const float* b_base = sB + (buf * KT_N + wn * 64 + l31) * KT_LD + 4 * lh;
+#pragma unroll
+            for (int kk = 0; kk < KT_K / 8; ++kk) {
+                // lanes 0-31 hold k = 8kk+j, lanes 32-63 k = 8kk+4+j of their row: one ds_read_b128 feeds 4 MFMAs
+                f32x4 a0 = *reinterpret_cast<const f32x4*>(a_base + kk * 8);
+                f32x4 a1 = *reinterpret_cast<const f32x4*>(a_base + 32 * KT_LD + kk * 8);
+                f32x4 b0 = *reinterpret_cast<const f32x4*>(b_base + kk * 8);
+                f32x4 b1 = *reinterpret_cast<const f32x4*>(b_base + 32 * KT_LD + kk * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+                }
+            }
+            if (kc + 1 < nk) swrite(buf ^ 1);
+            __syncthreads();
+        }
+
+        // ---- fused top-k epilogue -------------------------------------------------------------
+        // acc[mt][nt][r] = dot(store row row0 + wm*64 + mt*32 + (r&3) + 8*(r>>2) + 4*lh,
+        //                      query     q0   + wn*64 + nt*32 + l31)
+        // The tile buffers are free now: park the 128x128 score tile in them, query-major
+        // (S[q][row], row stride KS_LD), then ONE thread per query filters its 128 scores against the
+        // k-th best it carries in a register and inserts the rare survivors into its list.
+        const int rowlimit = (int)min((int64_t)KT_M, chunk_end - row0);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rl = wm * 64 + mt * 32 + 8 * g + 4 * lh;   // rows rl..rl+3 = registers 4g..4g+3
+                f32x4 v0, v1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float s0 = acc[mt][0][4 * g + i], s1 = acc[mt][1][4 * g + i];
+                    if (p.l2) {
+                        const float yn = p.ynorm[min(row0 + rl + i, p.n - 1)];
+                        s0 = 2.f * s0 - yn;
+                        s1 = 2.f * s1 - yn;
+                    }
+                    v0[i] = s0;
+                    v1[i] = s1;
+                }
+                *reinterpret_cast<f32x4*>(sS + (wn * 64 + l31) * KS_LD + rl) = v0;
+                *reinterpret_cast<f32x4*>(sS + (wn * 64 + 32 + l31) * KS_LD + rl) = v1;
+            }
+        __syncthreads();
+        if (tid < KT_N && q0 + tid < p.nq) {
+            const float* srow = sS + tid * KS_LD;
+            for (int c = 0; c < rowlimit; c += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(srow + c);
+                const float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                if (vm >= my_thr) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float sc = v[i];
+                        const int id = (int)(row0 + c + i);
+                        if (c + i < rowlimit && sc >= my_thr && better(sc, id, my_ls[k - 1], my_li[k - 1])) {
+                            int pos = k - 1;
+                            while (pos > 0 && better(sc, id, my_ls[pos - 1], my_li[pos - 1])) {
+                                my_ls[pos] = my_ls[pos - 1];
+                                my_li[pos] = my_li[pos - 1];
+                                --pos;
+                            }
+                            my_ls[pos] = sc;
+                            my_li[pos] = id;
+                            my_thr = my_ls[k - 1];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- P-way merge of sorted partial lists ------------------------------------------------------------
+// element (part, q, j): score at score[part*sp + q*sq + j].  Lists are sorted best-first.
+// MODE 0: internal partials (descending score; int32 local idx; output transform by metric)
+// MODE 1: public merge of final results (L2 ascending distance / IP descending; int64 idx; no transform)
+struct MergeParams {
+    const float* score;
+    const void* idx;
+    int64_t sp, sq;       // strides in elements
+    int n_parts;
+    int64_t nq;
+    int k;                // entries per input list and per output list
+    int l2;
+    const float* qnorm;   // MODE 0, L2: |q|^2
+    int64_t id_base;      // MODE 0
+    float* out_dist;      // [nq, k]
+    int64_t* out_idx;     // [nq, k]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_topk_merge(MergeParams p) {
+    extern __shared__ int s_pos_all[];   // [4 waves][n_parts]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+    if (q >= p.nq) return;
+    int* s_pos = s_pos_all + wave * p.n_parts;
+    for (int i = lane; i < p.n_parts; i += 64) s_pos[i] = 0;
+    // (a wave only touches its own s_pos slice: program order within the wave is enough)
+    const bool asc = (MODE == 1) && p.l2;
+    for (int o = 0; o < p.k; ++o) {
+        float bs = -INFINITY;     // key: larger is better
+        int64_t bi = INT64_MAX;
+        int bp = -1;
+        for (int part = lane; part < p.n_parts; part += 64) {
+            const int pos = s_pos[part];
+            if (pos >= p.k) continue;
+            const int64_t off = part * p.sp + q * p.sq + pos;
+            float s = p.score[off];
+            int64_t id;
+            if (MODE == 0) {
+                const int v = reinterpret_cast<const int*>(p.idx)[off];
+                id = v == IDX_SENTINEL ? INT64_MAX : (int64_t)v;
+            } else {
+                const int64_t v = reinterpret_cast<const int64_t*>(p.idx)[off];
+                id = v < 0 ? INT64_MAX : v;
+            }
+            if (id == INT64_MAX) continue;   // sentinel: list exhausted
+            const float key = asc ? -s : s;
+            if (bp < 0 || key > bs || (key == bs && id < bi)) { bs = key; bi = id; bp = part; }
+        }
+        // wave arg-best
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+            const float os = __shfl_xor(bs, ofs, 64);
+            const int64_t oi = __shfl_xor(bi, ofs, 64);
+            const int op = __shfl_xor(bp, ofs, 64);
+            const bool take = op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi));
+            if (take) { bs = os; bi = oi; bp = op; }
+        }
+        if (bp >= 0 && (bp & 63) == lane) s_pos[bp] += 1;
+        if (lane == 0) {
+            float d;
+            int64_t id;
+            if (bp < 0) {
+                id = -1;
+                d = p.l2 ? INFINITY : -INFINITY;
+            } else if (MODE == 0) {
+                id = bi + p.id_base;
+                d = p.l2 ? fmaxf(0.f, p.qnorm[q] - bs) : bs;
+            } else {
+                id = bi;
+                d = asc ? -bs : bs;
+            }
+            p.out_dist[q * p.k + o] = d;
+            p.out_idx[q * p.k + o] = id;
+        }
+    }
+}
+
+// ---- append path ----------------------------------------------------------------------------------
+// one wave per row.  mode 0: copy; 1: copy + ynorm = sum x^2; 2: x / (sqrt(sum x^2) + 1e-12)
+__global__ __launch_bounds__(256) void k_rows_prepare(const float* in, float* out, float* ynorm, int64_t n, int dim, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(in + row * dim);
+    f32x4* dst = reinterpret_cast<f32x4*>(out + row * dim);
+    const int nv = dim >> 2;
+    float ss = 0.f;
+    if (mode != 0) {
+        for (int i = lane; i < nv; i += 64) {
+            const f32x4 v = src[i];
+            ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+        ss = wave_sum(ss);
+    }
+    if (mode == 2) {
+        const float den = sqrtf(ss) + 1e-12f;
+        for (int i = lane; i < nv; i += 64) {
+            f32x4 v = src[i];
+            v[0] = v[0] / den; v[1] = v[1] / den; v[2] = v[2] / den; v[3] = v[3] / den;
+            dst[i] = v;
+        }
+    } else {
+        if (in != out)
+            for (int i = lane; i < nv; i += 64) dst[i] = src[i];
+        if (mode == 1 && lane == 0) ynorm[row] = ss;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ db, const int64_t* __restrict__ idx,
+                                                     int64_t n_out, int64_t ntotal, int64_t id_base, int dim,
+                                                     float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t o = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= n_out) return;
+    const int64_t r = idx[o] - id_base;
+    const bool ok = idx[o] >= 0 && r >= 0 && r < ntotal;
+    f32x4* dst = reinterpret_cast<f32x4*>(out + o * dim);
+    const f32x4* src = reinterpret_cast<const f32x4*>(db + (ok ? r : 0) * dim);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (int i = lane; i < (dim >> 2); i += 64) dst[i] = ok ? src[i] : z;
+}
+
+constexpr size_t knn_lds_bytes() { return sizeof(float) * (2 * KT_M * KT_LD + 2 * KT_N * KT_LD); }
+static_assert(KT_N * KS_LD <= 2 * KT_M * KT_LD + 2 * KT_N * KT_LD, "score tile must fit in the tile buffers");
+
+}  // namespace
+
+// ---- handle -------------------------------------------------------------------------------------------
+struct radad_knn_s {
+    int dim = 0, metric = 0, device = 0;
+    int64_t id_base = 0;
+    int64_t ntotal = 0, capacity = 0;
+    float* rows = nullptr;
+    float* ynorm = nullptr;
+    // search workspace (grown on demand, reused)
+    void* ws = nullptr;
+    size_t ws_bytes = 0;
+    int last_qtiles = 0, last_splits = 0;
+    std::mutex mu;
+};
+
+static int knn_realloc(radad_knn_t h, int64_t cap) {
+    float* nrows = nullptr;
+    float* nnorm = nullptr;
+    if (hipMalloc(&nrows, (size_t)cap * h->dim * sizeof(float)) != hipSuccess) {
+        radad_set_error("hipMalloc of %lld x %d rows failed", (long long)cap, h->dim);
+        return RADAD_ENOMEM;
+    }
+    if (h->metric == RADAD_METRIC_L2 && hipMalloc(&nnorm, (size_t)cap * sizeof(float)) != hipSuccess) {
+        (void)hipFree(nrows);
+        radad_set_error("hipMalloc of %lld norms failed", (long long)cap);
+        return RADAD_ENOMEM;
+    }
+    if (h->ntotal > 0) {
+        RADAD_HIP_CHECK(hipMemcpy(nrows, h->rows, (size_t)h->ntotal * h->dim * sizeof(float), hipMemcpyDeviceToDevice));
+        if (nnorm) RADAD_HIP_CHECK(hipMemcpy(nnorm, h->ynorm, (size_t)h->ntotal * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    if (h->rows) (void)hipFree(h->rows);
+    if (h->ynorm) (void)hipFree(h->ynorm);
+    h->rows = nrows;
+    h->ynorm = nnorm;
+    h->capacity = cap;
+    return RADAD_OK;
+}
+
+// geometric growth so repeated add() calls (vector_database.py:134-138 adds 10 000 rows at a time) stay O(n)
+static int knn_grow(radad_knn_t h, int64_t need) {
+    if (need <= h->capacity) return RADAD_OK;
+    int64_t cap = std::max<int64_t>(need, h->capacity + h->capacity / 2);
+    return knn_realloc(h, std::max<int64_t>(cap, 1024));
+}
+
+static int knn_workspace(radad_knn_t h, size_t bytes) {
+    if (bytes <= h->ws_bytes) return RADAD_OK;
+    if (h->ws) (void)hipFree(h->ws);
+    h->ws = nullptr;
+    h->ws_bytes = 0;
+    if (hipMalloc(&h->ws, bytes) != hipSuccess) {
+        radad_set_error("hipMalloc of %zu workspace bytes failed", bytes);
+        return RADAD_ENOMEM;
+    }
+    h->ws_bytes = bytes;
+    return RADAD_OK;
+}
+
+extern "C" {
+
+int radad_knn_create(int dim, int metric, int device, int64_t id_base, radad_knn_t* out) {
+    RADAD_REQUIRE(out != nullptr, "radad_knn_create: out is NULL");
+    RADAD_REQUIRE(dim > 0 && (dim % 4) == 0, "radad_knn_create: dim must be a positive multiple of 4 (got %d)", dim);
+    RADAD_REQUIRE(metric >= 0 && metric <= 2, "radad_knn_create: unsupported metric %d", metric);
+    int ndev = 0;
+    RADAD_HIP_CHECK(hipGetDeviceCount(&ndev));
+    RADAD_REQUIRE(device >= 0 && device < ndev, "radad_knn_create: device %d not in [0,%d)", device, ndev);
+    radad_knn_s* h = new (std::nothrow) radad_knn_s();
+    if (!h) { radad_set_error("out of host memory"); return RADAD_ENOMEM; }
+    h->dim = dim; h->metric = metric; h->device = device; h->id_base = id_base;
+    *out = h;
+    return RADAD_OK;
+}
+
+int radad_knn_destroy(radad_knn_t h) {
+    if (!h) return RADAD_OK;
+    {
+        DeviceGuard g(h->device);
+        if (h->rows) (void)hipFree(h->rows);
+        if (h->ynorm) (void)hipFree(h->ynorm);
+        if (h->ws) (void)hipFree(h->ws);
+    }
+    delete h;
+    return RADAD_OK;
+}
+
+int radad_knn_dim(radad_knn_t h, int* dim) { RADAD_REQUIRE(h && dim, "NULL argument"); *dim = h->dim; return RADAD_OK; }
+int radad_knn_metric(radad_knn_t h, int* metric) { RADAD_REQUIRE(h && metric, "NULL argument"); *metric = h->metric; return RADAD_OK; }
+int radad_knn_ntotal(radad_knn_t h, int64_t* n) { RADAD_REQUIRE(h && n, "NULL argument"); *n = h->ntotal; return RADAD_OK; }
+
+int radad_knn_reserve(radad_knn_t h, int64_t capacity) {
+    RADAD_REQUIRE(h, "NULL handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    if (capacity <= h->capacity) return RADAD_OK;
+    RADAD_HIP_CHECK(hipDeviceSynchronize());
+    return knn_realloc(h, capacity);
+}
+
+int radad_knn_add(radad_knn_t h, const float* rows_dev, int64_t n, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    RADAD_REQUIRE(n >= 0, "radad_knn_add: n < 0");
+    if (n == 0) return RADAD_OK;
+    RADAD_REQUIRE(rows_dev, "radad_knn_add: rows is NULL");
+    RADAD_REQUIRE(h->ntotal + n < (int64_t)IDX_SENTINEL, "radad_knn_add: more than 2^31-2 rows per store (shard it)");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (h->ntotal + n > h->capacity) {
+        RADAD_HIP_CHECK(hipStreamSynchronize(st));   // the old buffers may still be in use on `st`
+        int rc = knn_grow(h, h->ntotal + n);
+        if (rc) return rc;
+    }
+    const int mode = h->metric == RADAD_METRIC_COSINE ? 2 : (h->metric == RADAD_METRIC_L2 ? 1 : 0);
+    float* dst = h->rows + h->ntotal * h->dim;
+    float* yn = h->ynorm ? h->ynorm + h->ntotal : nullptr;
+    const unsigned grid = (unsigned)ceil_div64(n, 4);
+    hipLaunchKernelGGL(k_rows_prepare, dim3(grid), dim3(256), 0, st, rows_dev, dst, yn, n, h->dim, mode);
+    RADAD_HIP_CHECK(hipGetLastError());
+    h->ntotal += n;
+    return RADAD_OK;
+}
+
+int radad_knn_add_host(radad_knn_t h, const float* rows_host, int64_t n) {
+    RADAD_REQUIRE(h, "NULL handle");
+    if (n == 0) return RADAD_OK;
+    RADAD_REQUIRE(rows_host && n > 0, "radad_knn_add_host: bad rows/n");
+    float* tmp = nullptr;
+    {
+        DeviceGuard g(h->device);
+        const size_t bytes = (size_t)n * h->dim * sizeof(float);
+        if (hipMalloc(&tmp, bytes) != hipSuccess) { radad_set_error("hipMalloc of staging buffer failed"); return RADAD_ENOMEM; }
+        hipError_t e = hipMemcpy(tmp, rows_host, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(tmp); radad_set_error("H2D copy failed: %s", hipGetErrorString(e)); return RADAD_EHIP; }
+    }
+    int rc = radad_knn_add(h, tmp, n, nullptr);
+    {
+        DeviceGuard g(h->device);
+        hipError_t e = hipStreamSynchronize(nullptr);
+        (void)hipFree(tmp);
+        if (rc == RADAD_OK && e != hipSuccess) { radad_set_error("add failed: %s", hipGetErrorString(e)); rc = RADAD_EHIP; }
+    }
+    return rc;
+}
+
+// choose the launch geometry: enough equal splits to put >= 2 workgroups on each of the 256 CUs
+static void knn_geometry(int64_t n, int64_t nq, int* n_qtiles, int* n_splits, int64_t* chunk_rows) {
+    const int qt = (int)ceil_div64(nq, KT_N);
+    const int64_t tiles = ceil_div64(n, KT_M);
+    int64_t want = ceil_div64(512, qt);            // splits so that qt*splits ~ 512 workgroups
+    want = std::min<int64_t>(want, tiles);
+    want = std::max<int64_t>(8, ceil_div64(want, 8) * 8);
+    want = std::min<int64_t>(want, 1024);
+    const int64_t tiles_per = ceil_div64(tiles, want);
+    *n_qtiles = qt;
+    *n_splits = (int)want;
+    *chunk_rows = tiles_per * KT_M;
+}
+
+int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev, int64_t* out_idx_dev,
+                     void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    RADAD_REQUIRE(k >= 1 && k <= RADAD_KNN_MAX_K, "radad_knn_search: k=%d outside [1,%d]", k, RADAD_KNN_MAX_K);
+    RADAD_REQUIRE(nq >= 0 && nq < (1ll << 31) - KT_N, "radad_knn_search: bad nq");
+    if (nq == 0) return RADAD_OK;
+    RADAD_REQUIRE(q_dev && out_dist_dev && out_idx_dev, "radad_knn_search: NULL buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+
+    int n_qtiles, n_splits;
+    int64_t chunk_rows;
+    knn_geometry(std::max<int64_t>(h->ntotal, 1), nq, &n_qtiles, &n_splits, &chunk_rows);
+    h->last_qtiles = n_qtiles;
+    h->last_splits = n_splits;
+
+    // workspace: [qn: nq*dim] (cosine) | [qnorm: nq] (L2) | part_score | part_idx
+    const size_t qn_bytes = h->metric == RADAD_METRIC_COSINE ? (size_t)nq * h->dim * sizeof(float) : 0;
+    const size_t qnorm_bytes = (((size_t)nq * sizeof(float)) + 255) & ~(size_t)255;
+    const size_t part_elems = (size_t)nq * n_splits * k;
+    const size_t off_qnorm = (qn_bytes + 255) & ~(size_t)255;
+    const size_t off_ps = off_qnorm + qnorm_bytes;
+    const size_t off_pi = off_ps + ((part_elems * sizeof(float) + 255) & ~(size_t)255);
+    const size_t total = off_pi + part_elems * sizeof(int);
+    if (total > h->ws_bytes) {
+        RADAD_HIP_CHECK(hipStreamSynchronize(st));
+        int rc = knn_workspace(h, total);
+        if (rc) return rc;
+    }
+    char* ws = (char*)h->ws;
+    float* qn = (float*)ws;
+    float* qnorm = (float*)(ws + off_qnorm);
+    float* ps = (float*)(ws + off_ps);
+    int* pi = (int*)(ws + off_pi);
+
+    const float* q_use = q_dev;
+    const unsigned rgrid = (unsigned)ceil_div64(nq, 4);
+    if (h->metric == RADAD_METRIC_COSINE) {
+        hipLaunchKernelGGL(k_rows_prepare, dim3(rgrid), dim3(256), 0, st, q_dev, qn, (float*)nullptr, nq, h->dim, 2);
+        q_use = qn;
+    } else if (h->metric == RADAD_METRIC_L2) {
+        // mode 1 with in == out: only the norms are written
+        hipLaunchKernelGGL(k_rows_prepare, dim3(rgrid), dim3(256), 0, st, q_dev, const_cast<float*>(q_dev), qnorm, nq,
+                           h->dim, 1);
+    }
+    RADAD_HIP_CHECK(hipGetLastError());
+
+    KnnParams p;
+    p.db = h->rows; p.ynorm = h->ynorm; p.q = q_use; p.n = h->ntotal; p.nq = (int)nq; p.dim = h->dim; p.k = k;
+    p.l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0;
+    p.n_qtiles = n_qtiles; p.n_splits = n_splits; p.chunk_rows = chunk_rows; p.part_score = ps; p.part_idx = pi;
+    // 73 728 B of dynamic LDS > the 64 KB default: raise the limit (per device, so on every call)
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes());
+    RADAD_HIP_CHECK(attr);
+    hipLaunchKernelGGL(k_knn_f32, dim3((unsigned)(n_qtiles * n_splits)), dim3(KNN_THREADS), knn_lds_bytes(), st, p);
+    RADAD_HIP_CHECK(hipGetLastError());
+
+    MergeParams m;
+    m.score = ps; m.idx = pi; m.sp = k; m.sq = (int64_t)n_splits * k; m.n_parts = n_splits; m.nq = nq; m.k = k;
+    m.l2 = p.l2; m.qnorm = qnorm; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
+    hipLaunchKernelGGL(k_topk_merge<0>, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 4 * n_splits * sizeof(int), st, m);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+int radad_knn_search_host(radad_knn_t h, const float* q_host, int64_t nq, int k, float* out_dist_host,
+                          int64_t* out_idx_host) {
+    RADAD_REQUIRE(h, "NULL handle");
+    if (nq == 0) return RADAD_OK;
+    RADAD_REQUIRE(q_host && out_dist_host && out_idx_host && nq > 0 && k >= 1, "radad_knn_search_host: bad argument");
+    DeviceGuard g(h->device);
+    float *dq = nullptr, *dd = nullptr;
+    int64_t* di = nullptr;
+    const size_t qb = (size_t)nq * h->dim * sizeof(float);
+    int rc = RADAD_OK;
+    if (hipMalloc(&dq, qb) != hipSuccess || hipMalloc(&dd, (size_t)nq * k * sizeof(float)) != hipSuccess ||
+        hipMalloc(&di, (size_t)nq * k * sizeof(int64_t)) != hipSuccess) {
+        radad_set_error("hipMalloc of search staging buffers failed");
+        rc = RADAD_ENOMEM;
+    }
+    if (rc == RADAD_OK && hipMemcpy(dq, q_host, qb, hipMemcpyHostToDevice) != hipSuccess) { radad_set_error("H2D copy failed"); rc = RADAD_EHIP; }
+    if (rc == RADAD_OK) rc = radad_knn_search(h, dq, nq, k, dd, di, nullptr);
+    if (rc == RADAD_OK && (hipMemcpy(out_dist_host, dd, (size_t)nq * k * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess ||
+                           hipMemcpy(out_idx_host, di, (size_t)nq * k * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess)) {
+        radad_set_error("D2H copy failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = RADAD_EHIP;
+    }
+    if (dq) (void)hipFree(dq);
+    if (dd) (void)hipFree(dd);
+    if (di) (void)hipFree(di);
+    return rc;
+}
+
+int radad_knn_reconstruct(radad_knn_t h, const int64_t* idx_dev, int64_t n, float* out_dev, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    if (n == 0) return RADAD_OK;
+    RADAD_REQUIRE(idx_dev && out_dev && n > 0, "radad_knn_reconstruct: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, (hipStream_t)stream, h->rows, idx_dev,
+                       n, h->ntotal, h->id_base, h->dim, out_dev);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+int radad_knn_reconstruct_host(radad_knn_t h, const int64_t* idx_host, int64_t n, float* out_host) {
+    RADAD_REQUIRE(h, "NULL handle");
+    if (n == 0) return RADAD_OK;
+    RADAD_REQUIRE(idx_host && out_host && n > 0, "radad_knn_reconstruct_host: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    // small n (pipeline.py:503 fetches K rows per query): copy row by row straight from the store
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t r = idx_host[i] - h->id_base;
+        float* dst = out_host + i * h->dim;
+        if (idx_host[i] < 0 || r < 0 || r >= h->ntotal) { memset(dst, 0, sizeof(float) * h->dim); continue; }
+        RADAD_HIP_CHECK(hipMemcpy(dst, h->rows + r * h->dim, sizeof(float) * h->dim, hipMemcpyDeviceToHost));
+    }
+    return RADAD_OK;
+}
+
+int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, int* block_threads) {
+    RADAD_REQUIRE(h, "NULL handle");
+    if (n_query_tiles) *n_query_tiles = h->last_qtiles;
+    if (n_db_splits) *n_db_splits = h->last_splits;
+    if (block_threads) *block_threads = KNN_THREADS;
+    return RADAD_OK;
+}
+
+// ---- snapshot: "RADADKNN" | u32 version | i32 dim | i32 metric | i64 ntotal | rows fp32 (already normalised for cosine)
+int radad_knn_save(radad_knn_t h, const char* path) {
+    RADAD_REQUIRE(h && path, "radad_knn_save: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    FILE* f = fopen(path, "wb");
+    if (!f) { radad_set_error("cannot open %s for writing", path); return RADAD_EIO; }
+    const char magic[8] = {'R', 'A', 'D', 'A', 'D', 'K', 'N', 'N'};
+    const uint32_t ver = 1;
+    const int32_t dim = h->dim, metric = h->metric;
+    const int64_t nt = h->ntotal;
+    bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(&ver, 4, 1, f) == 1 && fwrite(&dim, 4, 1, f) == 1 &&
+              fwrite(&metric, 4, 1, f) == 1 && fwrite(&nt, 8, 1, f) == 1;
+    const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / ((int64_t)h->dim * 4));
+    std::vector<float> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(nt, 1)) * h->dim);
+    for (int64_t r = 0; ok && r < nt; r += chunk) {
+        const int64_t m = std::min<int64_t>(chunk, nt - r);
+        if (hipMemcpy(buf.data(), h->rows + r * h->dim, (size_t)m * h->dim * 4, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = fwrite(buf.data(), 4, (size_t)m * h->dim, f) == (size_t)m * h->dim;
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { radad_set_error("write to %s failed", path); return RADAD_EIO; }
+    return RADAD_OK;
+}
+
+int radad_knn_load(radad_knn_t h, const char* path) {
+    RADAD_REQUIRE(h && path, "radad_knn_load: NULL argument");
+    FILE* f = fopen(path, "rb");
+    if (!f) { radad_set_error("cannot open %s", path); return RADAD_EIO; }
+    char magic[8]; uint32_t ver = 0; int32_t dim = 0, metric = 0; int64_t nt = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "RADADKNN", 8) == 0 && fread(&ver, 4, 1, f) == 1 && ver == 1 &&
+              fread(&dim, 4, 1, f) == 1 && fread(&metric, 4, 1, f) == 1 && fread(&nt, 8, 1, f) == 1;
+    if (!ok || dim != h->dim || metric != h->metric || nt < 0) {
+        fclose(f);
+        radad_set_error("%s: bad header or dim/metric mismatch (file dim %d metric %d, handle dim %d metric %d)", path, dim,
+                        metric, h->dim, h->metric);
+        return RADAD_EIO;
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    RADAD_HIP_CHECK(hipDeviceSynchronize());
+    h->ntotal = 0;
+    int rc = knn_grow(h, nt);
+    if (rc) { fclose(f); return rc; }
+    const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / ((int64_t)h->dim * 4));
+    std::vector<float> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(nt, 1)) * h->dim);
+    for (int64_t r = 0; r < nt; r += chunk) {
+        const int64_t m = std::min<int64_t>(chunk, nt - r);
+        if (fread(buf.data(), 4, (size_t)m * h->dim, f) != (size_t)m * h->dim) { fclose(f); radad_set_error("%s: truncated", path); return RADAD_EIO; }
+        hipError_t e = hipMemcpy(h->rows + r * h->dim, buf.data(), (size_t)m * h->dim * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { fclose(f); radad_set_error("H2D copy failed: %s", hipGetErrorString(e)); return RADAD_EHIP; }
+    }
+    fclose(f);
+    if (h->metric == RADAD_METRIC_L2 && nt > 0) {
+        // rows are stored as added: recompute |y|^2 (mode 1, in place)
+        hipLaunchKernelGGL(k_rows_prepare, dim3((unsigned)ceil_div64(nt, 4)), dim3(256), 0, nullptr, h->rows, h->rows, h->ynorm,
+                           nt, h->dim, 1);
+        RADAD_HIP_CHECK(hipGetLastError());
+        RADAD_HIP_CHECK(hipDeviceSynchronize());
+    }
+    h->ntotal = nt;
+    return RADAD_OK;
+}
+
+int radad_topk_merge(int metric, const float* in_dist_dev, const int64_t* in_idx_dev, int n_parts, int64_t nq, int k,
+                     float* out_dist_dev, int64_t* out_idx_dev, int device, void* stream) {
+    RADAD_REQUIRE(metric >= 0 && metric <= 2, "radad_topk_merge: bad metric");
+    RADAD_REQUIRE(n_parts >= 1 && n_parts <= 4096 && k >= 1 && k <= RADAD_KNN_MAX_K && nq >= 0, "radad_topk_merge: bad shape");
+    if (nq == 0) return RADAD_OK;
+    RADAD_REQUIRE(in_dist_dev && in_idx_dev && out_dist_dev && out_idx_dev, "radad_topk_merge: NULL buffer");
+    DeviceGuard g(device);
+    MergeParams m;
+    m.score = in_dist_dev; m.idx = in_idx_dev; m.sp = nq * k; m.sq = k; m.n_parts = n_parts; m.nq = nq; m.k = k;
+    m.l2 = metric == RADAD_METRIC_L2; m.qnorm = nullptr; m.id_base = 0; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
+    hipLaunchKernelGGL(k_topk_merge<1>, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 4 * n_parts * sizeof(int),
+                       (hipStream_t)stream, m);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int device, void* stream) {
+    RADAD_REQUIRE(dim > 0 && dim % 4 == 0 && n >= 0, "radad_rownorm: bad shape");
+    if (n == 0) return RADAD_OK;
+    RADAD_REQUIRE(in_dev && out_dev, "radad_rownorm: NULL buffer");
+    DeviceGuard g(device);
+    hipLaunchKernelGGL(k_rows_prepare, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, (hipStream_t)stream, in_dev, out_dev,
+                       (float*)nullptr, n, dim, 2);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,181 @@
+"""Feature extractors behind the reference's protocol (`.feature_dim`, `.extract_features(segments)`),
+feature_extractor.py:6-170, selected by `build_feature_extractor` (pipeline.py:54-65).
+
+The reference's three extractors are a HuggingFace front-end plus a PRETRAINED transformer fetched by
+model name (feature_extractor.py:14-15, :70-71, :131-132).  Those weights are not part of the repository, so
+this build's native extractor keeps the front-ends the reference calls -- per-segment zero-mean /
+unit-variance (HF Wav2Vec2FeatureExtractor) and the HF Whisper log-mel spectrogram -- and puts a dense
+frame projection [T,80] x [80,F] where the encoder forward sits.  Everything runs in csrc/embed.hip;
+`embed_clips` is the batched entry that replaces the nested loops of process_audio_batch.
+Any object with the same two members can still be plugged into the pipeline shell.
+"""
+import ctypes as C
+from typing import List, Sequence
+
+import numpy as np
+
+from . import _lib
+
+N_FFT, FFT_HOP, N_MELS, N_BINS = 400, 160, 80, 201
+
+
+def mel_filter_bank_slaney(n_bins: int = N_BINS, n_mels: int = N_MELS, fmin: float = 0.0, fmax: float = 8000.0,
+                           sr: int = 16000) -> np.ndarray:
+    """Slaney-scale, slaney-normalised triangular filters [n_bins, n_mels] -- the bank the HF Whisper
+    front-end builds (feature_extraction_whisper.py:94-103), float64."""
+    def hz2mel(f):
+        f = np.asarray(f, np.float64)
+        return np.where(f >= 1000.0, 15.0 + np.log(np.maximum(f, 1e-300) / 1000.0) * (27.0 / np.log(6.4)), 3.0 * f / 200.0)
+
+    def mel2hz(m):
+        m = np.asarray(m, np.float64)
+        return np.where(m >= 15.0, 1000.0 * np.exp((np.log(6.4) / 27.0) * (m - 15.0)), 200.0 * m / 3.0)
+
+    edges = mel2hz(np.linspace(hz2mel(fmin), hz2mel(fmax), n_mels + 2))
+    bins = np.linspace(0, sr // 2, n_bins)
+    width = np.diff(edges)
+    rel = edges[None, :] - bins[:, None]
+    tri = np.maximum(0.0, np.minimum(-rel[:, :-2] / width[:-1], rel[:, 2:] / width[1:]))
+    return tri * (2.0 / (edges[2:] - edges[:-2]))[None, :]
+
+
+def synthetic_projection(feat_dim: int, seed: int):
+    """Seeded stand-in for trained projection weights: W ~ N(0, 1/80), b ~ N(0, 0.01)."""
+    rng = np.random.default_rng(seed)
+    w = (rng.standard_normal((N_MELS, feat_dim)) / np.sqrt(N_MELS)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(feat_dim)).astype(np.float32)
+    return w, b
+
+
+class MelProjectionFeatureExtractor:
+    """normalise -> log-mel -> frame projection, on the GPU.
+
+    extract_features(segments) follows the reference protocol (list of 1-D arrays -> list of [T, F] tensors
+    on config.device, as Wav2Vec2FeatureExtractor.extract_features returns them, feature_extractor.py:21-52).
+    """
+
+    def __init__(self, config, levels=None, pool_mode=None, weights=None):
+        import torch
+        self.config = config
+        self.device = torch.device(config.device)
+        if self.device.type != "cuda":
+            raise RuntimeError("MelProjectionFeatureExtractor needs a ROCm device: the HIP path has no CPU fallback")
+        self.feature_dim = int(getattr(config, "feature_dim", 512))
+        self.segment_length = int(config.segment_length * config.sample_rate)
+        self.hop_length = int(self.segment_length * (1 - config.segment_overlap))
+        self.levels = list(levels if levels is not None else config.tpp_levels)
+        mode = pool_mode if pool_mode is not None else config.tpp_pooling_type
+        if mode not in ("max", "avg"):
+            raise ValueError(f"Unsupported pooling type: {mode}")           # pooling.py:81
+        self.pool_mode = mode
+        if weights is None:
+            path = getattr(config, "melproj_weights_path", None)
+            if path:
+                z = np.load(path)
+                weights = (z["w"], z["b"])
+            else:
+                weights = synthetic_projection(self.feature_dim, int(getattr(config, "melproj_seed", 20251003)))
+        w, b = (np.ascontiguousarray(weights[0], np.float32), np.ascontiguousarray(weights[1], np.float32))
+        if w.shape != (N_MELS, self.feature_dim) or b.shape != (self.feature_dim,):
+            raise ValueError(f"projection weights must be [{N_MELS},{self.feature_dim}] and [{self.feature_dim}]")
+        self.proj_w, self.proj_b = w, b
+        self.mel_filters = np.ascontiguousarray(mel_filter_bank_slaney(), np.float32)
+
+        lib = _lib.load()
+        cfg = _lib.EmbedCfg()
+        cfg.segment_length, cfg.hop_length = self.segment_length, self.hop_length
+        cfg.normalize = 1 if getattr(config, "melproj_normalize", True) else 0
+        cfg.n_fft, cfg.fft_hop, cfg.n_mels = N_FFT, FFT_HOP, N_MELS
+        cfg.padded_samples = int(getattr(config, "melproj_padded_samples", 0) or 0)
+        cfg.feat_dim = self.feature_dim
+        cfg.n_levels = len(self.levels)
+        if not 1 <= len(self.levels) <= _lib.MAX_LEVELS:
+            raise ValueError(f"1..{_lib.MAX_LEVELS} pyramid levels supported")
+        for i, l in enumerate(self.levels):
+            cfg.levels[i] = int(l)
+        cfg.pool_mode = _lib.POOL_MAX if mode == "max" else _lib.POOL_AVG
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        h = C.c_void_p()
+        _lib.check(lib.radad_embed_create(C.byref(cfg), self.mel_filters.ctypes.data, w.ctypes.data, b.ctypes.data,
+                                          self._dev_index, C.byref(h)), "radad_embed_create")
+        self._h = h
+        self._lib = lib
+        d, t = C.c_int(), C.c_int()
+        _lib.check(lib.radad_embed_output_dim(h, C.byref(d)))
+        _lib.check(lib.radad_embed_num_frames(h, C.byref(t)))
+        self.output_dim, self.num_frames = d.value, t.value
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.radad_embed_destroy(h)
+            except Exception:
+                pass
+
+    # ---- batched device path --------------------------------------------------------------------------
+    def embed_clips(self, wave, clip_offsets: Sequence[int]):
+        """wave: 1-D float32 CUDA tensor holding the clips back to back; clip_offsets: B+1 host ints.
+        Returns the clip embeddings [B, sum(levels)*F] (segment -> embed of pipeline.py:392-414)."""
+        import torch
+        _lib.require_cuda(wave, "wave")
+        if wave.dtype != torch.float32 or not wave.is_contiguous():
+            wave = wave.contiguous().float()
+        offs = np.ascontiguousarray(np.asarray(clip_offsets, np.int64))
+        n_clips = len(offs) - 1
+        if n_clips < 0 or (n_clips >= 0 and (offs[0] < 0 or offs[-1] > wave.numel())):
+            raise ValueError("clip_offsets outside the wave buffer")
+        out = torch.empty((n_clips, self.output_dim), device=wave.device, dtype=torch.float32)
+        with torch.cuda.device(wave.device):
+            _lib.check(self._lib.radad_embed_forward(self._h, wave.data_ptr(), offs.ctypes.data_as(_lib.c_i64p),
+                                                     n_clips, out.data_ptr(), _lib.stream_ptr(wave.device)),
+                       "radad_embed_forward")
+        return out
+
+    def _stage(self, fn, segments, out_shape_tail):
+        """run a per-stage entry point on a list of host segments (each <= segment_length samples)"""
+        import torch
+        L = self.segment_length
+        valid = np.asarray([min(len(s), L) for s in segments], np.int32)
+        flat = np.zeros(len(segments) * L, np.float32)
+        for i, s in enumerate(segments):
+            if np.asarray(s).ndim != 1:
+                raise ValueError("Expected 1D audio array")
+            flat[i * L:i * L + valid[i]] = np.asarray(s, np.float32)[:valid[i]]
+        starts = np.arange(len(segments), dtype=np.int64) * L
+        wave = torch.from_numpy(flat).to(self.device)
+        out = torch.empty((len(segments),) + tuple(out_shape_tail), device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(fn(self._h, wave.data_ptr(), starts.ctypes.data_as(_lib.c_i64p), valid.ctypes.data_as(_lib.c_i32p),
+                          len(segments), out.data_ptr(), _lib.stream_ptr(self.device)))
+        return out
+
+    # ---- reference protocol ---------------------------------------------------------------------------
+    def extract_features(self, audio_segments: List[np.ndarray], move_to_cpu: bool = False):
+        """feature_extractor.py:21-52: list of S segments -> list of S tensors [T, F]."""
+        if len(audio_segments) == 0:
+            return []
+        feats = self._stage(self._lib.radad_embed_frame_features, audio_segments, (self.num_frames, self.feature_dim))
+        return [f.cpu() if move_to_cpu else f for f in feats]
+
+    def normalize_segments(self, audio_segments):
+        """HF Wav2Vec2FeatureExtractor zero-mean/unit-variance (feature_extraction_wav2vec2.py:95) -> [S, L]."""
+        return self._stage(self._lib.radad_embed_normalize, audio_segments, (self.segment_length,))
+
+    def log_mel(self, audio_segments):
+        """HF Whisper log-mel (feature_extraction_whisper.py:135-168) -> [S, T, 80] (HF: [S, 80, T])."""
+        return self._stage(self._lib.radad_embed_logmel, audio_segments, (self.num_frames, N_MELS))
+
+
+def build_feature_extractor(config):
+    """pipeline.py:54-65.  'melproj' is built natively; the reference's three kinds need pretrained
+    HuggingFace weights that this build does not ship -- plug an object with `.feature_dim` and
+    `.extract_features` into the pipeline instead."""
+    kind = getattr(config, "feature_extractor_type", "melproj").lower()
+    if kind == "melproj":
+        return MelProjectionFeatureExtractor(config)
+    if kind in ("wav2vec2", "whisper", "wavlm"):
+        raise NotImplementedError(
+            f"feature_extractor_type={kind!r} needs the pretrained HuggingFace encoder the reference downloads by "
+            "name (feature_extractor.py:14-15,70-71,131-132); pass your own extractor object to the pipeline.")
+    raise ValueError(f"Unsupported feature_extractor_type={kind!r} (use 'melproj' | 'wav2vec2' | 'whisper' | 'wavlm').")

@@ -1,0 +1,87 @@
+"""Row-sharded retrieval across the GPUs of one node (one process per GPU, torch.distributed; backend
+"nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The reference is single-GPU (vector_database.py:23 `device_id = 0`).  The store shards naturally: rank r owns a
+contiguous row range [base_r, base_r + n_r) and reports GLOBAL ids (id_base = base_r).  A search is
+  1. all_gather the per-rank query blocks            [Q_r, D] -> [Q, D]            (embeds are data-parallel)
+  2. local brute-force top-k of ALL queries on the shard                            (no communication)
+  3. all_gather the per-shard (dist, id) lists       2 x [Q, k] per rank          (12*Q*k bytes per rank: latency bound)
+  4. merge the G sorted lists per query by (distance, id)                          (radad_topk_merge)
+Both collectives are tiny, so on a fully connected xGMI node they are one-hop all-gathers.
+"""
+import ctypes as C
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+def shard_bounds(n_total: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous, balanced row range of `rank`: the first n_total % world_size ranks get one extra row."""
+    q, r = divmod(int(n_total), int(world_size))
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def hip_merge(metric: int, dists, idxs, k: int):
+    """dists/idxs: [G, Q, k] CUDA tensors -> merged ([Q,k] f32, [Q,k] i64) via radad_topk_merge."""
+    import torch
+    lib = _lib.load()
+    G, Q, kk = dists.shape
+    assert kk == k
+    out_d = torch.empty((Q, k), device=dists.device, dtype=torch.float32)
+    out_i = torch.empty((Q, k), device=dists.device, dtype=torch.int64)
+    d, i = dists.contiguous(), idxs.contiguous()
+    with torch.cuda.device(dists.device):
+        _lib.check(lib.radad_topk_merge(metric, d.data_ptr(), i.data_ptr(), G, Q, k, out_d.data_ptr(), out_i.data_ptr(),
+                                        dists.device.index, _lib.stream_ptr(dists.device)), "radad_topk_merge")
+    return out_d, out_i
+
+
+class ShardedSearch:
+    """Collective search over per-rank shards.
+
+    local_search(q [Q,D], k) -> (dist [Q,k], gid [Q,k]) must return GLOBAL ids (HipFlatIndex with id_base does).
+    merge(metric, dists [G,Q,k], idxs [G,Q,k], k) -> ([Q,k],[Q,k]); defaults to the HIP merge kernel.
+    Every rank must call `search` with the same k (and the same number of local queries unless
+    `uneven=True`, which pads to the max).
+    """
+
+    def __init__(self, local_search: Callable, metric: int, group=None, merge: Optional[Callable] = None):
+        import torch.distributed as dist
+        self.local_search = local_search
+        self.metric = int(metric)
+        self.group = group
+        self.merge = merge or hip_merge
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def gather_queries(self, q_local):
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return q_local
+        out = torch.empty((self.world * q_local.shape[0], q_local.shape[1]), device=q_local.device, dtype=q_local.dtype)
+        dist.all_gather_into_tensor(out, q_local.contiguous(), group=self.group)
+        return out
+
+    def search(self, q_local, k: int, return_all: bool = False):
+        """q_local [Q_r, D] (same Q_r on every rank) -> this rank's rows of the merged result
+        ([Q_r,k] distances, [Q_r,k] global ids); `return_all` returns all Q rows instead."""
+        import torch
+        import torch.distributed as dist
+        q_all = self.gather_queries(q_local)
+        d_loc, i_loc = self.local_search(q_all, k)
+        if self.world == 1:
+            return d_loc, i_loc
+        Q = q_all.shape[0]
+        d_all = torch.empty((self.world, Q, k), device=d_loc.device, dtype=d_loc.dtype)
+        i_all = torch.empty((self.world, Q, k), device=i_loc.device, dtype=i_loc.dtype)
+        dist.all_gather_into_tensor(d_all, d_loc.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(i_all, i_loc.contiguous(), group=self.group)
+        if return_all:
+            return self.merge(self.metric, d_all, i_all, k)
+        qr = q_local.shape[0]
+        sl = slice(self.rank * qr, (self.rank + 1) * qr)
+        return self.merge(self.metric, d_all[:, sl].contiguous(), i_all[:, sl].contiguous(), k)

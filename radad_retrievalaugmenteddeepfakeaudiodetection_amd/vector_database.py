@@ -1,0 +1,264 @@
+"""VectorDatabase -- same call surface as the reference's vector_database.py:8-272, with the faiss index
+object replaced by `HipFlatIndex`, a thin handle on the HBM-resident store in libradad_hip.so.
+
+What callers of the reference rely on and still find here:
+  * VectorDatabase(config): .add_vectors / .add_vectors_batch / .search_batch / .search / .save / .load,
+    attributes .vector_paths / .vector_labels / .vector_metadata, and the raw `.index`
+    (pipeline.py:445-446,480,495-506; app.py:67-76).
+  * .index.ntotal / .d / .is_trained / .add(np) / .search(np,k) / .reconstruct(i)  (faiss.IndexFlat surface
+    used at vector_database.py:124,138,151,169,181 and pipeline.py:465,503).
+Index types: 'L2' -> squared-L2 ascending; 'IP' -> inner product descending, with rows and queries
+L2-normalised first when config.normalize_for_ip (default True) i.e. cosine (vector_database.py:61-64,97,100-105).
+'IVF' (vector_database.py:65-70) is not built: brute force is the path this package accelerates.
+Device-resident variants (`search_device`, `reconstruct_batch`) let the pipeline skip the D2H/H2D hops.
+"""
+import ctypes as C
+import logging
+import os
+import pickle
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+class HipFlatIndex:
+    """Flat (exhaustive) index living in HBM.  Mirrors the slice of faiss.IndexFlat{L2,IP} the reference uses."""
+
+    is_trained = True   # flat indexes need no training (vector_database.py:124)
+
+    def __init__(self, d: int, metric: int, device: int = 0, id_base: int = 0):
+        self._lib = _lib.load()
+        self.d = int(d)
+        self.metric = int(metric)
+        self.device = int(device)
+        self.id_base = int(id_base)
+        h = C.c_void_p()
+        _lib.check(self._lib.radad_knn_create(self.d, self.metric, self.device, self.id_base, C.byref(h)), "radad_knn_create")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.radad_knn_destroy(h)
+            except Exception:
+                pass
+
+    @property
+    def ntotal(self) -> int:
+        n = C.c_int64()
+        _lib.check(self._lib.radad_knn_ntotal(self._h, C.byref(n)))
+        return n.value
+
+    def reserve(self, capacity: int):
+        _lib.check(self._lib.radad_knn_reserve(self._h, int(capacity)), "radad_knn_reserve")
+
+    # ---- host (numpy) surface: what faiss offers ---------------------------------------------------------
+    def add(self, x: np.ndarray):
+        x = np.ascontiguousarray(x, np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"add expects [n, {self.d}] float32, got {x.shape}")
+        _lib.check(self._lib.radad_knn_add_host(self._h, x.ctypes.data, x.shape[0]), "radad_knn_add_host")
+
+    def search(self, x: np.ndarray, k: int) -> Tuple[np.ndarray, np.ndarray]:
+        x = np.ascontiguousarray(x, np.float32)
+        if x.ndim != 2 or x.shape[1] != self.d:
+            raise ValueError(f"search expects [nq, {self.d}] float32, got {x.shape}")
+        D = np.empty((x.shape[0], k), np.float32)
+        I = np.empty((x.shape[0], k), np.int64)
+        _lib.check(self._lib.radad_knn_search_host(self._h, x.ctypes.data, x.shape[0], int(k), D.ctypes.data, I.ctypes.data),
+                   "radad_knn_search_host")
+        return D, I
+
+    def reconstruct(self, i: int) -> np.ndarray:
+        idx = np.asarray([int(i)], np.int64)
+        out = np.empty((1, self.d), np.float32)
+        _lib.check(self._lib.radad_knn_reconstruct_host(self._h, idx.ctypes.data, 1, out.ctypes.data))
+        return out[0]
+
+    # ---- device (torch) surface ---------------------------------------------------------------------------
+    def add_device(self, x):
+        import torch
+        _lib.require_cuda(x, "x")
+        x = x.contiguous().float()
+        if x.dim() != 2 or x.shape[1] != self.d:
+            raise ValueError(f"add expects [n, {self.d}], got {tuple(x.shape)}")
+        with torch.cuda.device(x.device):
+            _lib.check(self._lib.radad_knn_add(self._h, x.data_ptr(), x.shape[0], _lib.stream_ptr(x.device)), "radad_knn_add")
+
+    def search_device(self, q, k: int):
+        import torch
+        _lib.require_cuda(q, "q")
+        q = q.contiguous().float()
+        if q.dim() != 2 or q.shape[1] != self.d:
+            raise ValueError(f"search expects [nq, {self.d}], got {tuple(q.shape)}")
+        D = torch.empty((q.shape[0], k), device=q.device, dtype=torch.float32)
+        I = torch.empty((q.shape[0], k), device=q.device, dtype=torch.int64)
+        with torch.cuda.device(q.device):
+            _lib.check(self._lib.radad_knn_search(self._h, q.data_ptr(), q.shape[0], int(k), D.data_ptr(), I.data_ptr(),
+                                                  _lib.stream_ptr(q.device)), "radad_knn_search")
+        return D, I
+
+    def reconstruct_batch(self, idx):
+        """idx: int64 CUDA tensor of any shape -> [*idx.shape, d]; negative ids give zero rows."""
+        import torch
+        _lib.require_cuda(idx, "idx")
+        flat = idx.contiguous().to(torch.int64).reshape(-1)
+        out = torch.empty((flat.numel(), self.d), device=idx.device, dtype=torch.float32)
+        with torch.cuda.device(idx.device):
+            _lib.check(self._lib.radad_knn_reconstruct(self._h, flat.data_ptr(), flat.numel(), out.data_ptr(),
+                                                       _lib.stream_ptr(idx.device)), "radad_knn_reconstruct")
+        return out.reshape(*idx.shape, self.d)
+
+    def last_launch(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._lib.radad_knn_last_launch(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"query_tiles": a.value, "db_splits": b.value, "block_threads": c.value}
+
+    def save(self, path: str):
+        _lib.check(self._lib.radad_knn_save(self._h, os.fsencode(path)), "radad_knn_save")
+
+    def load(self, path: str):
+        _lib.check(self._lib.radad_knn_load(self._h, os.fsencode(path)), "radad_knn_load")
+
+
+class VectorDatabase:
+    """Store of clip embeddings + brute-force retrieval (vector_database.py:8-272)."""
+
+    def __init__(self, config):
+        self.config = config
+        self.index = None
+        self.vector_paths: List[str] = []
+        self.vector_labels: List = []
+        self.vector_metadata: Dict[str, list] = {}
+        self.db_path = os.path.join(config.vector_db_path, "faiss_index.bin")   # file names kept (vector_database.py:18-19)
+        self.metadata_path = os.path.join(config.vector_db_path, "metadata.pkl")
+        self.device_id = 0
+        os.makedirs(config.vector_db_path, exist_ok=True)
+        self._cosine = False
+        import torch
+        dev = torch.device(getattr(config, "device", "cuda"))
+        if dev.type == "cuda":
+            self.device_id = dev.index if dev.index is not None else torch.cuda.current_device()
+
+    # vector_database.py:56-97
+    def create_index(self, dimension: int, id_base: int = 0):
+        index_type = self.config.vector_db_index_type.upper()
+        self._cosine = (index_type == "IP") and bool(getattr(self.config, "normalize_for_ip", True))
+        if index_type == "L2":
+            metric = _lib.METRIC_L2
+        elif index_type == "IP":
+            metric = _lib.METRIC_COSINE if self._cosine else _lib.METRIC_IP
+        elif index_type == "IVF":
+            raise NotImplementedError("IVF (vector_database.py:65-70) is not built; use 'L2' or 'IP' (brute force)")
+        else:
+            raise ValueError(f"Unsupported index type: {index_type}")
+        self.index = HipFlatIndex(dimension, metric, self.device_id, id_base)
+        logging.info(f"Created HIP flat index on device {self.device_id} dim={dimension} type={index_type}")
+
+    # vector_database.py:108-151
+    def add_vectors_batch(self, vectors, paths: List[str], labels: List[int], metadata: Dict, batch_size: int = 10000):
+        if vectors.shape[0] == 0:
+            logging.warning("No vectors to add to database")
+            return
+        if self.index is None:
+            self.create_index(vectors.shape[1])
+        is_dev = hasattr(vectors, "is_cuda") and vectors.is_cuda
+        if not is_dev:
+            vectors = np.ascontiguousarray(np.asarray(vectors).astype(np.float32, copy=False))
+        total = vectors.shape[0]
+        added = 0
+        for start in range(0, total, batch_size):
+            end = min(start + batch_size, total)
+            try:
+                if is_dev:
+                    self.index.add_device(vectors[start:end])
+                else:
+                    self.index.add(vectors[start:end])     # normalisation for cosine happens in the add kernel
+                added += end - start
+                self.vector_paths.extend(paths[start:end])
+                self.vector_labels.extend(labels[start:end])
+                for key, values in metadata.items():
+                    self.vector_metadata.setdefault(key, [])
+                    vals = values[start:end] if hasattr(values, "__getitem__") else [values] * (end - start)
+                    self.vector_metadata[key].extend(vals)
+            except Exception as e:   # log-and-skip, as vector_database.py:147-149
+                logging.error(f"Error adding batch {start}-{end}: {e}")
+                continue
+        logging.info(f"Added {added}/{total} vectors. Index ntotal={self.index.ntotal}")
+
+    # vector_database.py:154-157
+    def add_vectors(self, vectors, paths: List[str], labels: List[int], metadata: Dict):
+        self.add_vectors_batch(vectors, paths, labels, metadata, getattr(self.config, "vector_add_batch_size", 10000))
+
+    # vector_database.py:159-182
+    def search_batch(self, query_vectors, k: int = None):
+        """numpy in -> (float32 [B,k], int64 [B,k]) numpy out, as the reference; a CUDA tensor in -> CUDA tensors out."""
+        if self.index is None:
+            raise ValueError("Vector database is empty. Build the database first.")
+        k = int(k if k is not None else getattr(self.config, "top_k", 5))
+        is_dev = hasattr(query_vectors, "is_cuda") and query_vectors.is_cuda
+        if not is_dev:
+            query_vectors = np.asarray(query_vectors)
+        if query_vectors.ndim == 1:
+            query_vectors = query_vectors.reshape(1, -1)
+        k = min(k, self.index.ntotal)
+        if k <= 0:
+            logging.warning("No vectors available for search")
+            if is_dev:
+                import torch
+                return (torch.zeros((len(query_vectors), 0), dtype=torch.float32, device=query_vectors.device),
+                        torch.zeros((len(query_vectors), 0), dtype=torch.int64, device=query_vectors.device))
+            return np.zeros((len(query_vectors), 0), dtype=np.float32), np.zeros((len(query_vectors), 0), dtype=np.int64)
+        if is_dev:
+            return self.index.search_device(query_vectors, k)
+        return self.index.search(query_vectors.astype(np.float32, copy=False), k)
+
+    # vector_database.py:185-188
+    def search(self, query_vector, k: int = None):
+        distances, indices = self.search_batch(query_vector.reshape(1, -1), k)
+        return (distances[0] if len(distances) > 0 else np.array([]), indices[0] if len(indices) > 0 else np.array([]))
+
+    # vector_database.py:190-216 (own snapshot format instead of faiss.write_index; same metadata keys)
+    def save(self):
+        try:
+            if self.index is None:
+                logging.warning("No index to save.")
+                return
+            self.index.save(self.db_path)
+            meta = {"paths": self.vector_paths, "labels": self.vector_labels, "metadata": self.vector_metadata,
+                    "index_type": self.config.vector_db_index_type, "dimension": self.index.d}
+            with open(self.metadata_path, "wb") as f:
+                pickle.dump(meta, f)
+            logging.info(f"Saved index to {self.db_path} with {self.index.ntotal} vectors")
+        except Exception as e:
+            logging.error(f"Error saving vector database: {e}")
+
+    # vector_database.py:218-242
+    def load(self):
+        try:
+            if not (os.path.exists(self.db_path) and os.path.exists(self.metadata_path)):
+                logging.warning("No saved vector database found")
+                return
+            with open(self.metadata_path, "rb") as f:
+                meta = pickle.load(f)
+            self.vector_paths, self.vector_labels, self.vector_metadata = meta["paths"], meta["labels"], meta["metadata"]
+            self.create_index(int(meta["dimension"]))
+            self.index.load(self.db_path)
+            logging.info(f"Loaded index; ntotal={self.index.ntotal}")
+        except Exception as e:
+            logging.error(f"Error loading vector database: {e}")
+
+    # vector_database.py:245-256
+    def get_gpu_memory_usage(self):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                free, total = torch.cuda.mem_get_info(self.device_id)
+                used = total - free
+                return {"used": int(used), "total": int(total), "utilization": float(used / total)}
+        except Exception:
+            pass
+        return None
