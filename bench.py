@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- clips/sec of the segment -> embed -> retrieve hot path on N MI355X of one node.
+
+Workload (BASELINE.json metric: "clips/sec (segment+embed+retrieve) @1M x 512 DB"):
+  per GPU and step: 1024 synthetic 4 s / 16 kHz clips (3 segments each), resident in HBM ->
+  k_logmel + k_proj_pool (F = 512, pyramid levels [1] => D = 512) -> cosine top-10 against a
+  1 000 000 x 512 fp32 reference store.  With N > 1 ranks the store is row-sharded (1M/N rows each), every
+  rank embeds its own 1024 clips, the embeddings are all-gathered (RCCL), each rank scores ALL N*1024
+  queries against its shard, the per-shard top-10 lists are all-gathered and merged.  Per-GPU work is
+  therefore constant in N ("weak"); value = N*1024 clips / max-over-ranks step time.
+
+One JSON line on rank 0 (contract in the task statement), including
+  roofline     : the dominant kernel (k_knn_f32, fp32 MFMA bound) timed with HIP events on the launch stream
+  cpu_baseline : the oracle (numpy port of the same pipeline) timed on this host on a bounded sample,
+                 which doubles as the full-size parity check of the GPU result (ids bit-exact on the sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CLIPS_PER_GPU = 1024
+CLIP_SAMPLES = 64000
+DB_ROWS = 1_000_000
+DIM = 512
+TOP_K = 10
+AUDIO_SEED, DB_SEED, NOISE_SEED = 1234, 4321, 99
+PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
+PEAK_HBM_GBPS = 8000.0
+
+
+def planted_row(j, c, n_total):
+    """global row that holds near-duplicate c of global query j"""
+    return (j * 977 + c * 350003 + 17) % n_total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU per step")
+    ap.add_argument("--db-rows", type=int, default=DB_ROWS, help="total reference-store rows")
+    ap.add_argument("--cpu-sample", type=int, default=192, help="clips in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import ShardedSearch, shard_bounds
+    lib = _lib.load()
+
+    cfg = R.Config()
+    cfg.update(device=dev, tpp_levels=[1], tpp_pooling_type="max", feature_dim=DIM, vector_db_index_type="IP")
+    fe = R.MelProjectionFeatureExtractor(cfg)
+    B = args.clips
+    n_total = args.db_rows
+    lo, hi = shard_bounds(n_total, world, rank)
+
+    # ---- inputs, resident in HBM before the timed region -------------------------------------------------
+    wave = torch.empty(B * CLIP_SAMPLES, device=dev, dtype=torch.float32)
+    _lib.check(lib.radad_synth_audio(wave.data_ptr(), rank * B, B, CLIP_SAMPLES, AUDIO_SEED, local_rank, _lib.stream_ptr(dev)))
+    offsets = np.arange(B + 1, dtype=np.int64) * CLIP_SAMPLES
+    emb0 = fe.embed_clips(wave, offsets)                              # also the first warm-up of the embed kernels
+    if world > 1:
+        all_emb = torch.empty((world * B, DIM), device=dev)
+        dist.all_gather_into_tensor(all_emb, emb0)
+    else:
+        all_emb = emb0
+    rows = torch.empty((hi - lo, DIM), device=dev, dtype=torch.float32)
+    _lib.check(lib.radad_synth_rows(rows.data_ptr(), lo, hi - lo, DIM, DB_SEED, local_rank, _lib.stream_ptr(dev)))
+    # plant two near-duplicates of every query so that the top of each list is known and non-trivial
+    Q = world * B
+    noise = torch.empty((2 * Q, DIM), device=dev)
+    _lib.check(lib.radad_synth_rows(noise.data_ptr(), 0, 2 * Q, DIM, NOISE_SEED, local_rank, _lib.stream_ptr(dev)))
+    jj = torch.arange(Q, device=dev)
+    scale = all_emb.norm(dim=1, keepdim=True) / (DIM ** 0.5)
+    for c, eps in ((0, 0.05), (1, 0.10)):
+        g = (jj * 977 + c * 350003 + 17) % n_total
+        mine = (g >= lo) & (g < hi)
+        rows[g[mine] - lo] = all_emb[mine] + eps * scale[mine] * noise[c * Q:(c + 1) * Q][mine]
+    vdb = R.VectorDatabase(cfg)
+    vdb.create_index(DIM, id_base=lo)                                 # cosine: rows are normalised by the add kernel
+    vdb.index.reserve(hi - lo)
+    vdb.index.add_device(rows)
+    torch.cuda.synchronize()
+    del noise
+    searcher = ShardedSearch(vdb.index.search_device, vdb.index.metric)
+
+    def step():
+        emb = fe.embed_clips(wave, offsets)
+        return emb, searcher.search(emb, TOP_K)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    fe.profile(True)
+    vdb.index.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        emb, (D, I) = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    knn_ms = vdb.index.profile_read()
+    lm_ms, pp_ms = fe.profile_read()
+    fe.profile(False)
+    vdb.index.profile(False)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- correctness of the timed result (cheap, every rank): the planted rows lead every list ----------------
+    mine = torch.arange(rank * B, (rank + 1) * B, device=dev)
+    want0 = (mine * 977 + 17) % n_total
+    planted_ok = bool((I[:, 0] == want0).all().item())
+
+    ms_step = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+    knn_avg = float(np.mean(knn_ms)) if knn_ms else float("nan")
+    flops = 2.0 * Q * (hi - lo) * DIM                                   # algorithmic FLOPs of one scan launch
+    alg_bytes = 4.0 * (hi - lo) * DIM + 4.0 * Q * DIM + 12.0 * Q * TOP_K
+    achieved = flops / (knn_avg * 1e-3) / 1e12
+    out = {
+        "metric": "clips/sec (segment+embed+retrieve) @1Mx512 DB",
+        "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{B} clips/GPU x 4 s @16 kHz (3 segments), F=512, levels=[1], cosine top-{TOP_K}, "
+                               f"{n_total} x {DIM} fp32 store row-sharded over {world} GPU(s)",
+                   "clips_per_gpu": B, "db_rows": n_total, "dim": DIM, "k": TOP_K, "parallelism": f"shard{world}",
+                   "planted_neighbours_found": planted_ok},
+        "roofline": {"kernel": "k_knn_f32", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                     "kernel_ms": round(knn_avg, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+                     "hbm_GBps_algorithmic": round(alg_bytes / (knn_avg * 1e-3) / 1e9, 1),
+                     "launch": vdb.index.last_launch()},
+        "kernels_ms": {"k_logmel": round(float(np.mean(lm_ms)), 4) if lm_ms else None,
+                       "k_proj_pool": round(float(np.mean(pp_ms)), 4) if pp_ms else None, "k_knn_f32": round(knn_avg, 4)},
+    }
+
+    # ---- CPU baseline = the oracle on this host, bounded sample; also the full-size parity check ------------------
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        from oracle import radad_oracle as O
+        ns = min(args.cpu_sample, B)
+        wav_h = wave[: ns * CLIP_SAMPLES].cpu().numpy().reshape(ns, CLIP_SAMPLES)
+        db_h = rows.cpu().numpy()
+        cores = len(os.sched_getaffinity(0))
+        t0 = time.perf_counter()
+        emb_ref = O.embed_clips(list(wav_h), fe.segment_length, fe.hop_length, fe.proj_w, fe.proj_b, (1,), "max")
+        t_embed = time.perf_counter() - t0
+        od, oi = O.knn(db_h, emb_ref, TOP_K, "COSINE", chunk=65536)
+        t_cpu = time.perf_counter() - t0
+        emb_err = float(np.abs(emb[:ns].cpu().numpy() - emb_ref).max())
+        ids_equal = bool(np.array_equal(I[:ns].cpu().numpy(), oi))
+        dist_err = float(np.abs(D[:ns].cpu().numpy() - od).max())
+        out["cpu_baseline"] = {"value": round(ns / t_cpu, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+                               "sample": f"{ns} of the {B} clips against the full {n_total} x {DIM} store "
+                                         f"(numpy float64 oracle: embed {t_embed:.1f} s + kNN {t_cpu - t_embed:.1f} s)",
+                               "parity_on_sample": {"ids_bit_exact": ids_equal, "max_abs_dist_err": dist_err,
+                                                    "max_abs_embed_err": emb_err}}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,6 +97,12 @@ int radad_knn_load(radad_knn_t h, const char* path);
  * Query the launch geometry of the last search (for roofline accounting in bench.py). */
 int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, int* block_threads);
 
+/* HIP-event timing of the scan kernel (k_knn_f32) alone, on the stream each search is enqueued on:
+ * enable -> every search records an event pair around the kernel launch (ring of 64); read synchronises on the
+ * recorded events and returns the kernel durations in ms, oldest first.  For bench.py's roofline line. */
+int radad_knn_profile(radad_knn_t h, int enable);
+int radad_knn_profile_read(radad_knn_t h, float* ms_out, int cap, int* n_out);
+
 /* merge P partial top-k lists per query into one (used for the multi-GPU all-gather merge and
  * internally by search):  in_dist/in_idx are [P, nq, k]; metric decides the order; (dist, idx)
  * lexicographic, idx -1 entries sort last. */
@@ -146,6 +152,10 @@ int64_t radad_segment_count(int64_t n_samples, int32_t segment_length, int32_t h
  * out_dev [n_clips, output_dim] fp32.  (process_audio_batch, pipeline.py:392-414, minus file loading) */
 int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_host, int64_t n_clips,
                         float* out_dev, void* stream);
+
+/* same HIP-event timing for the two embedding kernels (k_logmel, k_proj_pool) of radad_embed_forward */
+int radad_embed_profile(radad_embed_t h, int enable);
+int radad_embed_profile_read(radad_embed_t h, float* logmel_ms_out, float* projpool_ms_out, int cap, int* n_out);
 
 /* stage entry points, for parity with the reference's per-stage functions ------------------------ */
 /* zero-mean/unit-var of S segments: seg s = wave_dev[seg_start_host[s] .. +seg_valid_host[s]) zero

@@ -52,6 +52,10 @@ SIGNATURES = {
     "radad_knn_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "radad_knn_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "radad_knn_last_launch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "radad_knn_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "radad_knn_profile_read": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.POINTER(C.c_int)]),
+    "radad_embed_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "radad_embed_profile_read": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(C.c_int)]),
     "radad_topk_merge": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_void_p]),
     "radad_rownorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

@@ -58,3 +58,41 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Ring of HIP event pairs recorded around one kernel launch on the caller's stream (bench.py's roofline leg).
+struct EventRing {
+    static constexpr int N = 64;
+    hipEvent_t a[N], b[N];
+    bool created = false, enabled = false;
+    int count = 0;
+    int enable(bool on) {
+        if (on && !created) {
+            for (int i = 0; i < N; ++i) {
+                if (hipEventCreate(&a[i]) != hipSuccess || hipEventCreate(&b[i]) != hipSuccess) return RADAD_EHIP;
+            }
+            created = true;
+        }
+        enabled = on;
+        count = 0;
+        return RADAD_OK;
+    }
+    void begin(hipStream_t st) { if (enabled) (void)hipEventRecord(a[count % N], st); }
+    void end(hipStream_t st) { if (enabled) { (void)hipEventRecord(b[count % N], st); ++count; } }
+    int read(float* out, int cap, int* n_out) {
+        const int n = count < N ? count : N;
+        int w = 0;
+        for (int i = 0; i < n && w < cap; ++i) {
+            const int slot = (count - n + i) % N;
+            if (hipEventSynchronize(b[slot]) != hipSuccess) return RADAD_EHIP;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, a[slot], b[slot]) != hipSuccess) return RADAD_EHIP;
+            out[w++] = ms;
+        }
+        if (n_out) *n_out = w;
+        return RADAD_OK;
+    }
+    void destroy() {
+        if (created) for (int i = 0; i < N; ++i) { (void)hipEventDestroy(a[i]); (void)hipEventDestroy(b[i]); }
+        created = false;
+    }
+};

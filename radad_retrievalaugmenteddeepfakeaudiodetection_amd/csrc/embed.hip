@@ -279,16 +279,18 @@ __global__ __launch_bounds__(PP_THREADS, 2) void k_proj_pool(ProjPoolParams p) {
         wf[kk] = *reinterpret_cast<const f32x4*>(p.wfrag + (((int64_t)ft * 10 + kk) * 64 + lane) * 4);
     const float bias = p.bias[feat];
 
-    if (!FRAMES_OUT)
-        for (int i = tid; i < nbins * PP_FEATS; i += PP_THREADS) sclip[i] = 0.f;
+    // spool/sclip columns are wave-private (only lanes lh == 0 of the owning wave touch column fl), so no
+    // barrier is needed between a segment's pooling, its fold into the clip sum and the next segment's reset
+    if (!FRAMES_OUT && lh == 0)
+        for (int b = 0; b < nbins; ++b) sclip[b * PP_FEATS + fl] = 0.f;
 
     const int64_t s_begin = p.clip_seg[clip], s_end = p.clip_seg[clip + 1];
     for (int64_t s = s_begin; s < s_end; ++s) {
         const float smax = p.seg_max[s];
         const float floor_v = smax - 8.0f;
-        if (!FRAMES_OUT) {
+        if (!FRAMES_OUT && lh == 0) {
             const float init = p.pool_mode == RADAD_POOL_MAX ? -INFINITY : 0.f;
-            for (int i = tid; i < nbins * PP_FEATS; i += PP_THREADS) spool[i] = init;
+            for (int b = 0; b < nbins; ++b) spool[b * PP_FEATS + fl] = init;
         }
         for (int f0 = 0; f0 < p.T; f0 += PP_FB) {
             const int fcount = min(PP_FB, p.T - f0);
@@ -475,6 +477,7 @@ struct radad_embed_s {
     std::vector<int64_t> plan_key;       // the clip_offsets the cached plan was built from
     int64_t plan_nseg = 0;
     DevBuf seg_start, seg_valid, clip_seg, logmel, seg_max, misc;
+    EventRing prof_logmel, prof_pool;
     std::mutex mu;
 };
 
@@ -552,7 +555,9 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.seg_len = h->cfg.segment_length; p.normalize = h->cfg.normalize; p.padded = h->padded; p.nf = h->nf;
     p.basis = h->basis; p.fbfrag = h->fbfrag; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
     p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out;
+    h->prof_logmel.begin(st);
     hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
+    h->prof_logmel.end(st);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
 }
@@ -683,6 +688,8 @@ int radad_embed_destroy(radad_embed_t h) {
         if (h->levels_dev) (void)hipFree(h->levels_dev);
         h->seg_start.release(); h->seg_valid.release(); h->clip_seg.release(); h->logmel.release(); h->seg_max.release();
         h->misc.release();
+        h->prof_logmel.destroy();
+        h->prof_pool.destroy();
     }
     delete h;
     return RADAD_OK;
@@ -706,9 +713,33 @@ int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* c
     ProjPoolParams p;
     fill_projpool(h, p);
     p.out = out_dev;
+    h->prof_pool.begin(st);
     hipLaunchKernelGGL(k_proj_pool<false>, dim3((unsigned)n_clips, (unsigned)((h->cfg.feat_dim + PP_FEATS - 1) / PP_FEATS)), dim3(PP_THREADS),
                        projpool_lds_bytes(), st, p);
+    h->prof_pool.end(st);
     RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+int radad_embed_profile(radad_embed_t h, int enable) {
+    RADAD_REQUIRE(h, "NULL handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    int rc = h->prof_logmel.enable(enable != 0);
+    if (!rc) rc = h->prof_pool.enable(enable != 0);
+    if (rc) radad_set_error("hipEventCreate failed");
+    return rc;
+}
+
+int radad_embed_profile_read(radad_embed_t h, float* logmel_ms_out, float* projpool_ms_out, int cap, int* n_out) {
+    RADAD_REQUIRE(h && logmel_ms_out && projpool_ms_out && cap >= 0, "radad_embed_profile_read: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    int n1 = 0, n2 = 0;
+    int rc = h->prof_logmel.read(logmel_ms_out, cap, &n1);
+    if (!rc) rc = h->prof_pool.read(projpool_ms_out, cap, &n2);
+    if (rc) { radad_set_error("reading profile events failed"); return rc; }
+    if (n_out) *n_out = n1 < n2 ? n1 : n2;
     return RADAD_OK;
 }
 

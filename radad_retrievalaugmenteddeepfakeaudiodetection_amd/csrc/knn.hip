@@ -353,6 +353,7 @@ struct radad_knn_s {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     int last_qtiles = 0, last_splits = 0;
+    EventRing prof;
     std::mutex mu;
 };
 
@@ -423,6 +424,7 @@ int radad_knn_destroy(radad_knn_t h) {
         if (h->rows) (void)hipFree(h->rows);
         if (h->ynorm) (void)hipFree(h->ynorm);
         if (h->ws) (void)hipFree(h->ws);
+        h->prof.destroy();
     }
     delete h;
     return RADAD_OK;
@@ -557,7 +559,9 @@ int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float
     const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes());
     RADAD_HIP_CHECK(attr);
+    h->prof.begin(st);
     hipLaunchKernelGGL(k_knn_f32, dim3((unsigned)(n_qtiles * n_splits)), dim3(KNN_THREADS), knn_lds_bytes(), st, p);
+    h->prof.end(st);
     RADAD_HIP_CHECK(hipGetLastError());
 
     MergeParams m;
@@ -622,6 +626,24 @@ int radad_knn_reconstruct_host(radad_knn_t h, const int64_t* idx_host, int64_t n
         RADAD_HIP_CHECK(hipMemcpy(dst, h->rows + r * h->dim, sizeof(float) * h->dim, hipMemcpyDeviceToHost));
     }
     return RADAD_OK;
+}
+
+int radad_knn_profile(radad_knn_t h, int enable) {
+    RADAD_REQUIRE(h, "NULL handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    int rc = h->prof.enable(enable != 0);
+    if (rc) radad_set_error("hipEventCreate failed");
+    return rc;
+}
+
+int radad_knn_profile_read(radad_knn_t h, float* ms_out, int cap, int* n_out) {
+    RADAD_REQUIRE(h && ms_out && cap >= 0, "radad_knn_profile_read: bad argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    int rc = h->prof.read(ms_out, cap, n_out);
+    if (rc) radad_set_error("reading profile events failed");
+    return rc;
 }
 
 int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, int* block_threads) {

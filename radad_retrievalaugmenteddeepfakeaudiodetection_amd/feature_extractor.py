@@ -132,6 +132,15 @@ class MelProjectionFeatureExtractor:
                        "radad_embed_forward")
         return out
 
+    def profile(self, enable: bool = True):
+        _lib.check(self._lib.radad_embed_profile(self._h, 1 if enable else 0), "radad_embed_profile")
+
+    def profile_read(self):
+        """(k_logmel ms list, k_proj_pool ms list) of the recorded radad_embed_forward calls"""
+        a, b, n = (C.c_float * 64)(), (C.c_float * 64)(), C.c_int()
+        _lib.check(self._lib.radad_embed_profile_read(self._h, a, b, 64, C.byref(n)), "radad_embed_profile_read")
+        return [float(a[i]) for i in range(n.value)], [float(b[i]) for i in range(n.value)]
+
     def _stage(self, fn, segments, out_shape_tail):
         """run a per-stage entry point on a list of host segments (each <= segment_length samples)"""
         import torch

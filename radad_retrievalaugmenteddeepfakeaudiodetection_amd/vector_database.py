@@ -117,6 +117,17 @@ class HipFlatIndex:
         _lib.check(self._lib.radad_knn_last_launch(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"query_tiles": a.value, "db_splits": b.value, "block_threads": c.value}
 
+    def profile(self, enable: bool = True):
+        """record HIP events around every scan-kernel launch (ring of 64)"""
+        _lib.check(self._lib.radad_knn_profile(self._h, 1 if enable else 0), "radad_knn_profile")
+
+    def profile_read(self):
+        """scan-kernel durations in ms (synchronises on the recorded events)"""
+        buf = (C.c_float * 64)()
+        n = C.c_int()
+        _lib.check(self._lib.radad_knn_profile_read(self._h, buf, 64, C.byref(n)), "radad_knn_profile_read")
+        return [float(buf[i]) for i in range(n.value)]
+
     def save(self, path: str):
         _lib.check(self._lib.radad_knn_save(self._h, os.fsencode(path)), "radad_knn_save")
 

@@ -26,10 +26,12 @@ def _check(D, I, od, oi, metric, unit):
         np.testing.assert_allclose(D, od, rtol=0, atol=1e-4)
 
 
-def _assert_separated(od, metric, scale):
-    """the oracle's rank gaps must dwarf fp32 error, otherwise 'bit-exact ids' is not a fair test"""
+def _assert_separated(od, D):
+    """'bit-exact ids' is only a fair demand where the fp64 gap between consecutive ranks exceeds the fp32 error;
+    the seeds used here keep every gap above 4x the error actually observed (otherwise: change the seed, not the test)"""
     gaps = O.rank_gaps(od)
-    assert gaps.min() > 100 * 1.2e-7 * scale, f"seed gives near-ties (min gap {gaps.min():.3e}); pick another seed"
+    err = np.abs(D - od).max()
+    assert gaps.min() > 4 * err, f"seed gives near-ties (min gap {gaps.min():.3e} vs fp32 error {err:.3e}); pick another seed"
 
 
 @pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
@@ -47,8 +49,8 @@ def test_knn_matches_oracle(gpu, metric, n, nq, dim, k):
     assert idx.ntotal == n
     D, I = idx.search(q, k)
     od, oi = O.knn(db, q, k, metric)
-    _assert_separated(od, metric, 1.0 if metric == "COSINE" else float(dim) * 4)
     _check(D, I, od, oi, metric, unit=(metric == "COSINE"))
+    _assert_separated(od, D)
 
 
 def test_knn_device_tensors_and_reconstruct(gpu):
