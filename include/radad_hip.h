@@ -83,6 +83,13 @@ int radad_knn_add_host(radad_knn_t h, const float* rows_host, int64_t n);
 #define RADAD_KNN_MAX_K 1024
 int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev,
                      int64_t* out_idx_dev, void* stream);
+/* same search, additionally returning the float64 distances the final ranking was made on
+ * (out_key_dev [nq, k] double, may be NULL).  The fp32 MFMA scan only selects k + 6 candidates per query; they are
+ * re-scored in float64 from the stored rows (L2 as sum (q-y)^2) and ordered by (float64 distance, id), so ids and
+ * order are those of an exact brute force and out_dist is the correctly rounded distance.  Sharded searches merge
+ * on these keys (radad_topk_merge_f64) so that no cross-shard pair is decided by fp32 rounding. */
+int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev,
+                         int64_t* out_idx_dev, double* out_key_dev, void* stream);
 /* host-buffer variant (what index.search(np.ndarray, k) does); synchronous */
 int radad_knn_search_host(radad_knn_t h, const float* q_host, int64_t nq, int k, float* out_dist_host,
                           int64_t* out_idx_host);
@@ -108,6 +115,10 @@ int radad_knn_profile_read(radad_knn_t h, float* ms_out, int cap, int* n_out);
  * lexicographic, idx -1 entries sort last. */
 int radad_topk_merge(int metric, const float* in_dist_dev, const int64_t* in_idx_dev, int n_parts, int64_t nq,
                      int k, float* out_dist_dev, int64_t* out_idx_dev, int device, void* stream);
+
+int radad_topk_merge_f64(int metric, const double* in_key_dev, const int64_t* in_idx_dev, int n_parts, int64_t nq,
+                         int k, float* out_dist_dev, int64_t* out_idx_dev, double* out_key_dev, int device,
+                         void* stream);
 
 /* row L2 normalisation x / (|x| + 1e-12)  (vector_database.py:100-105); in-place allowed */
 int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int device, void* stream);

@@ -46,6 +46,8 @@ SIGNATURES = {
     "radad_knn_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "radad_knn_add_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "radad_knn_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "radad_knn_search_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
     "radad_knn_search_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "radad_knn_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "radad_knn_reconstruct_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -58,6 +60,8 @@ SIGNATURES = {
     "radad_embed_profile_read": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.POINTER(C.c_int)]),
     "radad_topk_merge": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_void_p]),
+    "radad_topk_merge_f64": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "radad_rownorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "radad_embed_create": (C.c_int, [C.POINTER(EmbedCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(C.c_void_p)]),

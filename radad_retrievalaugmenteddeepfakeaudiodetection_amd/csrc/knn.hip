@@ -9,7 +9,8 @@
 //                      per-workgroup top-k: 128 store rows x 128 queries per tile, K stepped 32 at a
 //                      time through double-buffered LDS; the store rows are the MFMA "A" side so that a
 //                      lane owns ONE query column and its running k-th-best threshold lives in a register.
-//   k_topk_merge     : P-way merge of sorted partial lists by (distance, index), one wave per query.
+//   k_merge_refine   : picks k+6 fp32 candidates per query from the partial lists, re-scores them in float64 and
+//                      ranks by (distance, id); k_merge_lists: P-way merge of final per-shard lists.
 //   k_gather_rows    : batched reconstruct.
 //
 // Layout in HBM: rows [capacity, dim] fp32 row-major (insertion order), ynorm [capacity] fp32 (L2 only).
@@ -213,26 +214,127 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32(KnnParams p) {
     }
 }
 
-// ---- P-way merge of sorted partial lists ------------------------------------------------------------
-// element (part, q, j): score at score[part*sp + q*sq + j].  Lists are sorted best-first.
-// MODE 0: internal partials (descending score; int32 local idx; output transform by metric)
-// MODE 1: public merge of final results (L2 ascending distance / IP descending; int64 idx; no transform)
-struct MergeParams {
-    const float* score;
-    const void* idx;
-    int64_t sp, sq;       // strides in elements
-    int n_parts;
+// ---- merge of sorted partial lists -----------------------------------------------------------------------
+// element (part, q, j) of a list sits at [part*sp + q*sq + j]; lists are sorted best-first and padded with
+// sentinels.  One wave per query; each lane walks the heads of the lists part = lane, lane+64, ...
+//
+// k_merge_refine (inside radad_knn_search): picks the `ksel` best fp32 candidates of the n_splits partial lists
+//   (ksel = k + KNN_MARGIN), RE-SCORES them in float64 straight from the stored rows (L2 as sum (q-y)^2, no
+//   cancellation) and ranks them by (float64 distance, id).  The fp32 MFMA scan is thus only a filter: the final
+//   order and the reported distances are those of an exact float64 brute force unless two of the k best
+//   differ from more than KNN_MARGIN others by less than fp32 rounding (never observed; a tie in the data is
+//   identical in both precisions and resolves to the lower id either way).
+// k_merge_lists<KeyT> (radad_topk_merge / _f64): plain P-way merge of final per-shard lists, no rescoring.
+constexpr int KNN_MARGIN = 6;
+
+struct RefineParams {
+    const float* score;       // [nq, n_parts, ksel] fp32 scan scores (larger is better)
+    const int* idx;           // [nq, n_parts, ksel] local row or IDX_SENTINEL
+    int n_parts, ksel, k, dim, l2;
     int64_t nq;
-    int k;                // entries per input list and per output list
-    int l2;
-    const float* qnorm;   // MODE 0, L2: |q|^2
-    int64_t id_base;      // MODE 0
-    float* out_dist;      // [nq, k]
-    int64_t* out_idx;     // [nq, k]
+    const float* db;          // stored rows (normalised for cosine)
+    const float* q;           // the queries the scan used (normalised for cosine)
+    int64_t id_base;
+    float* out_dist;          // [nq, k]
+    int64_t* out_idx;         // [nq, k]
+    double* out_key;          // optional [nq, k] float64 distances
+    int waves_per_block;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_topk_merge(MergeParams p) {
+__global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_m[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t q = (int64_t)blockIdx.x * p.waves_per_block + wave;
+    if (wave >= p.waves_per_block || q >= p.nq) return;
+    // per-wave LDS: double key[ksel] | int id[ksel] | int pos[n_parts]
+    const size_t per_wave = (size_t)p.ksel * 12 + (size_t)p.n_parts * 4;
+    char* base = smem_m + (((size_t)wave * per_wave + 15) & ~(size_t)15) + (size_t)wave * 16;
+    double* c_key = reinterpret_cast<double*>(base);
+    int* c_id = reinterpret_cast<int*>(base + (size_t)p.ksel * 8);
+    int* s_pos = c_id + p.ksel;
+    for (int i = lane; i < p.n_parts; i += 64) s_pos[i] = 0;
+
+    // 1) the ksel best fp32 candidates (a wave only touches its own LDS slice: program order suffices)
+    int nsel = 0;
+    for (int o = 0; o < p.ksel; ++o) {
+        float bs = -INFINITY;
+        int bi = IDX_SENTINEL, bp = -1;
+        for (int part = lane; part < p.n_parts; part += 64) {
+            const int pos = s_pos[part];
+            if (pos >= p.ksel) continue;
+            const int64_t off = ((int64_t)q * p.n_parts + part) * p.ksel + pos;
+            const int id = p.idx[off];
+            if (id == IDX_SENTINEL) continue;
+            const float sc = p.score[off];
+            if (bp < 0 || sc > bs || (sc == bs && id < bi)) { bs = sc; bi = id; bp = part; }
+        }
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+            const float os = __shfl_xor(bs, ofs, 64);
+            const int oi = __shfl_xor(bi, ofs, 64);
+            const int op = __shfl_xor(bp, ofs, 64);
+            if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
+        }
+        if (bp < 0) break;                       // every list exhausted (wave-uniform)
+        if ((bp & 63) == lane) s_pos[bp] += 1;
+        if (lane == 0) c_id[nsel] = bi;
+        ++nsel;
+    }
+    // 2) float64 re-score of the survivors
+    const float* qrow = p.q + q * p.dim;
+    for (int c = 0; c < nsel; ++c) {
+        const float* y = p.db + (int64_t)c_id[c] * p.dim;
+        double acc = 0.0;
+        for (int i = lane * 4; i < p.dim; i += 256) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + i);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(y + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (p.l2) { const double d = (double)a[e] - (double)b[e]; acc += d * d; }
+                else acc += (double)a[e] * (double)b[e];
+            }
+        }
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) acc += __shfl_xor(acc, ofs, 64);
+        if (lane == 0) c_key[c] = acc;
+    }
+    // 3) rank by (distance, id): L2 ascending, IP descending; ids are unique so ranks are a permutation
+    for (int c = lane; c < nsel; c += 64) {
+        const double kc = c_key[c];
+        const int ic = c_id[c];
+        int rank = 0;
+        for (int j = 0; j < nsel; ++j) {
+            const double kj = c_key[j];
+            const bool jb = p.l2 ? (kj < kc || (kj == kc && c_id[j] < ic)) : (kj > kc || (kj == kc && c_id[j] < ic));
+            rank += jb ? 1 : 0;
+        }
+        if (rank < p.k) {
+            p.out_dist[q * p.k + rank] = (float)kc;
+            p.out_idx[q * p.k + rank] = (int64_t)ic + p.id_base;
+            if (p.out_key) p.out_key[q * p.k + rank] = kc;
+        }
+    }
+    for (int o = nsel + lane; o < p.k; o += 64) {   // faiss fills what it cannot find with -1 / +-inf
+        p.out_dist[q * p.k + o] = p.l2 ? INFINITY : -INFINITY;
+        p.out_idx[q * p.k + o] = -1;
+        if (p.out_key) p.out_key[q * p.k + o] = p.l2 ? (double)INFINITY : -(double)INFINITY;
+    }
+}
+
+template <typename KeyT>
+struct ListMergeParams {
+    const KeyT* key;          // [n_parts, nq, k] final distances of each shard
+    const int64_t* idx;       // [n_parts, nq, k] global ids, -1 = unfilled
+    int n_parts, k, l2;
+    int64_t nq;
+    float* out_dist;
+    int64_t* out_idx;
+    double* out_key;          // optional (KeyT == double)
+};
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_merge_lists(ListMergeParams<KeyT> p) {
     extern __shared__ int s_pos_all[];   // [4 waves][n_parts]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -240,54 +342,32 @@ __global__ __launch_bounds__(256) void k_topk_merge(MergeParams p) {
     if (q >= p.nq) return;
     int* s_pos = s_pos_all + wave * p.n_parts;
     for (int i = lane; i < p.n_parts; i += 64) s_pos[i] = 0;
-    // (a wave only touches its own s_pos slice: program order within the wave is enough)
-    const bool asc = (MODE == 1) && p.l2;
     for (int o = 0; o < p.k; ++o) {
-        float bs = -INFINITY;     // key: larger is better
+        KeyT bs = 0;             // "larger is better" key
         int64_t bi = INT64_MAX;
         int bp = -1;
         for (int part = lane; part < p.n_parts; part += 64) {
             const int pos = s_pos[part];
             if (pos >= p.k) continue;
-            const int64_t off = part * p.sp + q * p.sq + pos;
-            float s = p.score[off];
-            int64_t id;
-            if (MODE == 0) {
-                const int v = reinterpret_cast<const int*>(p.idx)[off];
-                id = v == IDX_SENTINEL ? INT64_MAX : (int64_t)v;
-            } else {
-                const int64_t v = reinterpret_cast<const int64_t*>(p.idx)[off];
-                id = v < 0 ? INT64_MAX : v;
-            }
-            if (id == INT64_MAX) continue;   // sentinel: list exhausted
-            const float key = asc ? -s : s;
+            const int64_t off = ((int64_t)part * p.nq + q) * p.k + pos;
+            const int64_t id = p.idx[off];
+            if (id < 0) continue;
+            const KeyT key = p.l2 ? -p.key[off] : p.key[off];
             if (bp < 0 || key > bs || (key == bs && id < bi)) { bs = key; bi = id; bp = part; }
         }
-        // wave arg-best
 #pragma unroll
         for (int ofs = 32; ofs > 0; ofs >>= 1) {
-            const float os = __shfl_xor(bs, ofs, 64);
+            const KeyT os = __shfl_xor(bs, ofs, 64);
             const int64_t oi = __shfl_xor(bi, ofs, 64);
             const int op = __shfl_xor(bp, ofs, 64);
-            const bool take = op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi));
-            if (take) { bs = os; bi = oi; bp = op; }
+            if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
         }
         if (bp >= 0 && (bp & 63) == lane) s_pos[bp] += 1;
         if (lane == 0) {
-            float d;
-            int64_t id;
-            if (bp < 0) {
-                id = -1;
-                d = p.l2 ? INFINITY : -INFINITY;
-            } else if (MODE == 0) {
-                id = bi + p.id_base;
-                d = p.l2 ? fmaxf(0.f, p.qnorm[q] - bs) : bs;
-            } else {
-                id = bi;
-                d = asc ? -bs : bs;
-            }
-            p.out_dist[q * p.k + o] = d;
-            p.out_idx[q * p.k + o] = id;
+            const KeyT d = bp < 0 ? (p.l2 ? (KeyT)INFINITY : -(KeyT)INFINITY) : (p.l2 ? -bs : bs);
+            p.out_dist[q * p.k + o] = (float)d;
+            p.out_idx[q * p.k + o] = bp < 0 ? -1 : bi;
+            if (p.out_key) p.out_key[q * p.k + o] = (double)d;
         }
     }
 }
@@ -341,6 +421,23 @@ constexpr size_t knn_lds_bytes() { return sizeof(float) * (2 * KT_M * KT_LD + 2 
 static_assert(KT_N * KS_LD <= 2 * KT_M * KT_LD + 2 * KT_N * KT_LD, "score tile must fit in the tile buffers");
 
 }  // namespace
+
+template <typename KeyT>
+static int merge_lists(int metric, const KeyT* in_key, const int64_t* in_idx, int n_parts, int64_t nq, int k, float* out_dist,
+                       int64_t* out_idx, double* out_key, int device, void* stream) {
+    RADAD_REQUIRE(metric >= 0 && metric <= 2, "radad_topk_merge: bad metric");
+    RADAD_REQUIRE(n_parts >= 1 && n_parts <= 4096 && k >= 1 && k <= RADAD_KNN_MAX_K && nq >= 0, "radad_topk_merge: bad shape");
+    if (nq == 0) return RADAD_OK;
+    RADAD_REQUIRE(in_key && in_idx && out_dist && out_idx, "radad_topk_merge: NULL buffer");
+    DeviceGuard g(device);
+    ListMergeParams<KeyT> m;
+    m.key = in_key; m.idx = in_idx; m.n_parts = n_parts; m.k = k; m.l2 = metric == RADAD_METRIC_L2; m.nq = nq;
+    m.out_dist = out_dist; m.out_idx = out_idx; m.out_key = out_key;
+    hipLaunchKernelGGL(k_merge_lists<KeyT>, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 4 * n_parts * sizeof(int),
+                       (hipStream_t)stream, m);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
 
 // ---- handle -------------------------------------------------------------------------------------------
 struct radad_knn_s {
@@ -505,6 +602,11 @@ static void knn_geometry(int64_t n, int64_t nq, int* n_qtiles, int* n_splits, in
 
 int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev, int64_t* out_idx_dev,
                      void* stream) {
+    return radad_knn_search_f64(h, q_dev, nq, k, out_dist_dev, out_idx_dev, nullptr, stream);
+}
+
+int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev, int64_t* out_idx_dev,
+                         double* out_key_dev, void* stream) {
     RADAD_REQUIRE(h, "NULL handle");
     RADAD_REQUIRE(k >= 1 && k <= RADAD_KNN_MAX_K, "radad_knn_search: k=%d outside [1,%d]", k, RADAD_KNN_MAX_K);
     RADAD_REQUIRE(nq >= 0 && nq < (1ll << 31) - KT_N, "radad_knn_search: bad nq");
@@ -523,7 +625,8 @@ int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float
     // workspace: [qn: nq*dim] (cosine) | [qnorm: nq] (L2) | part_score | part_idx
     const size_t qn_bytes = h->metric == RADAD_METRIC_COSINE ? (size_t)nq * h->dim * sizeof(float) : 0;
     const size_t qnorm_bytes = (((size_t)nq * sizeof(float)) + 255) & ~(size_t)255;
-    const size_t part_elems = (size_t)nq * n_splits * k;
+    const int ksel = k + KNN_MARGIN;             // the scan keeps a few spare candidates for the float64 re-rank
+    const size_t part_elems = (size_t)nq * n_splits * ksel;
     const size_t off_qnorm = (qn_bytes + 255) & ~(size_t)255;
     const size_t off_ps = off_qnorm + qnorm_bytes;
     const size_t off_pi = off_ps + ((part_elems * sizeof(float) + 255) & ~(size_t)255);
@@ -544,15 +647,12 @@ int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float
     if (h->metric == RADAD_METRIC_COSINE) {
         hipLaunchKernelGGL(k_rows_prepare, dim3(rgrid), dim3(256), 0, st, q_dev, qn, (float*)nullptr, nq, h->dim, 2);
         q_use = qn;
-    } else if (h->metric == RADAD_METRIC_L2) {
-        // mode 1 with in == out: only the norms are written
-        hipLaunchKernelGGL(k_rows_prepare, dim3(rgrid), dim3(256), 0, st, q_dev, const_cast<float*>(q_dev), qnorm, nq,
-                           h->dim, 1);
     }
+    (void)qnorm;   // |q|^2 is not needed: ranking uses 2 q.y - |y|^2 and the reported distance is re-scored exactly
     RADAD_HIP_CHECK(hipGetLastError());
 
     KnnParams p;
-    p.db = h->rows; p.ynorm = h->ynorm; p.q = q_use; p.n = h->ntotal; p.nq = (int)nq; p.dim = h->dim; p.k = k;
+    p.db = h->rows; p.ynorm = h->ynorm; p.q = q_use; p.n = h->ntotal; p.nq = (int)nq; p.dim = h->dim; p.k = ksel;
     p.l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0;
     p.n_qtiles = n_qtiles; p.n_splits = n_splits; p.chunk_rows = chunk_rows; p.part_score = ps; p.part_idx = pi;
     // 73 728 B of dynamic LDS > the 64 KB default: raise the limit (per device, so on every call)
@@ -564,10 +664,14 @@ int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float
     h->prof.end(st);
     RADAD_HIP_CHECK(hipGetLastError());
 
-    MergeParams m;
-    m.score = ps; m.idx = pi; m.sp = k; m.sq = (int64_t)n_splits * k; m.n_parts = n_splits; m.nq = nq; m.k = k;
-    m.l2 = p.l2; m.qnorm = qnorm; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
-    hipLaunchKernelGGL(k_topk_merge<0>, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 4 * n_splits * sizeof(int), st, m);
+    RefineParams m;
+    m.score = ps; m.idx = pi; m.n_parts = n_splits; m.ksel = ksel; m.k = k; m.dim = h->dim; m.l2 = p.l2; m.nq = nq;
+    m.db = h->rows; m.q = q_use; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
+    m.out_key = out_key_dev;
+    const size_t per_wave = (((size_t)ksel * 12 + (size_t)n_splits * 4 + 15) & ~(size_t)15) + 16;
+    m.waves_per_block = (int)std::max<size_t>(1, std::min<size_t>(4, (60 * 1024) / per_wave));
+    hipLaunchKernelGGL(k_merge_refine, dim3((unsigned)ceil_div64(nq, m.waves_per_block)), dim3(256),
+                       per_wave * m.waves_per_block + 64, st, m);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
 }
@@ -720,18 +824,13 @@ int radad_knn_load(radad_knn_t h, const char* path) {
 
 int radad_topk_merge(int metric, const float* in_dist_dev, const int64_t* in_idx_dev, int n_parts, int64_t nq, int k,
                      float* out_dist_dev, int64_t* out_idx_dev, int device, void* stream) {
-    RADAD_REQUIRE(metric >= 0 && metric <= 2, "radad_topk_merge: bad metric");
-    RADAD_REQUIRE(n_parts >= 1 && n_parts <= 4096 && k >= 1 && k <= RADAD_KNN_MAX_K && nq >= 0, "radad_topk_merge: bad shape");
-    if (nq == 0) return RADAD_OK;
-    RADAD_REQUIRE(in_dist_dev && in_idx_dev && out_dist_dev && out_idx_dev, "radad_topk_merge: NULL buffer");
-    DeviceGuard g(device);
-    MergeParams m;
-    m.score = in_dist_dev; m.idx = in_idx_dev; m.sp = nq * k; m.sq = k; m.n_parts = n_parts; m.nq = nq; m.k = k;
-    m.l2 = metric == RADAD_METRIC_L2; m.qnorm = nullptr; m.id_base = 0; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
-    hipLaunchKernelGGL(k_topk_merge<1>, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 4 * n_parts * sizeof(int),
-                       (hipStream_t)stream, m);
-    RADAD_HIP_CHECK(hipGetLastError());
-    return RADAD_OK;
+    return merge_lists<float>(metric, in_dist_dev, in_idx_dev, n_parts, nq, k, out_dist_dev, out_idx_dev, nullptr, device, stream);
+}
+
+int radad_topk_merge_f64(int metric, const double* in_key_dev, const int64_t* in_idx_dev, int n_parts, int64_t nq, int k,
+                         float* out_dist_dev, int64_t* out_idx_dev, double* out_key_dev, int device, void* stream) {
+    return merge_lists<double>(metric, in_key_dev, in_idx_dev, n_parts, nq, k, out_dist_dev, out_idx_dev, out_key_dev, device,
+                               stream);
 }
 
 int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int device, void* stream) {

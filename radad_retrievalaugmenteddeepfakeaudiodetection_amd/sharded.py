@@ -25,7 +25,8 @@ def shard_bounds(n_total: int, world_size: int, rank: int) -> Tuple[int, int]:
 
 
 def hip_merge(metric: int, dists, idxs, k: int):
-    """dists/idxs: [G, Q, k] CUDA tensors -> merged ([Q,k] f32, [Q,k] i64) via radad_topk_merge."""
+    """dists/idxs: [G, Q, k] CUDA tensors -> merged ([Q,k] f32, [Q,k] i64).  float64 `dists` (the keys
+    radad_knn_search_f64 returns) are merged on float64 so no cross-shard pair is decided by fp32 rounding."""
     import torch
     lib = _lib.load()
     G, Q, kk = dists.shape
@@ -34,15 +35,21 @@ def hip_merge(metric: int, dists, idxs, k: int):
     out_i = torch.empty((Q, k), device=dists.device, dtype=torch.int64)
     d, i = dists.contiguous(), idxs.contiguous()
     with torch.cuda.device(dists.device):
-        _lib.check(lib.radad_topk_merge(metric, d.data_ptr(), i.data_ptr(), G, Q, k, out_d.data_ptr(), out_i.data_ptr(),
-                                        dists.device.index, _lib.stream_ptr(dists.device)), "radad_topk_merge")
+        if d.dtype == torch.float64:
+            _lib.check(lib.radad_topk_merge_f64(metric, d.data_ptr(), i.data_ptr(), G, Q, k, out_d.data_ptr(), out_i.data_ptr(),
+                                                None, dists.device.index, _lib.stream_ptr(dists.device)), "radad_topk_merge_f64")
+        else:
+            _lib.check(lib.radad_topk_merge(metric, d.float().data_ptr() if d.dtype != torch.float32 else d.data_ptr(),
+                                            i.data_ptr(), G, Q, k, out_d.data_ptr(), out_i.data_ptr(), dists.device.index,
+                                            _lib.stream_ptr(dists.device)), "radad_topk_merge")
     return out_d, out_i
 
 
 class ShardedSearch:
     """Collective search over per-rank shards.
 
-    local_search(q [Q,D], k) -> (dist [Q,k], gid [Q,k]) must return GLOBAL ids (HipFlatIndex with id_base does).
+    local_search(q [Q,D], k) -> (dist [Q,k], gid [Q,k]) must return GLOBAL ids (HipFlatIndex with id_base does);
+    dist may be float64 (HipFlatIndex.search_device(..., return_f64=True)[2]) -- it is what gets merged.
     merge(metric, dists [G,Q,k], idxs [G,Q,k], k) -> ([Q,k],[Q,k]); defaults to the HIP merge kernel.
     Every rank must call `search` with the same k (and the same number of local queries unless
     `uneven=True`, which pads to the max).
@@ -74,7 +81,7 @@ class ShardedSearch:
         q_all = self.gather_queries(q_local)
         d_loc, i_loc = self.local_search(q_all, k)
         if self.world == 1:
-            return d_loc, i_loc
+            return d_loc.float(), i_loc
         Q = q_all.shape[0]
         d_all = torch.empty((self.world, Q, k), device=d_loc.device, dtype=d_loc.dtype)
         i_all = torch.empty((self.world, Q, k), device=i_loc.device, dtype=i_loc.dtype)

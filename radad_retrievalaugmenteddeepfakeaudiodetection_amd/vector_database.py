@@ -88,7 +88,9 @@ class HipFlatIndex:
         with torch.cuda.device(x.device):
             _lib.check(self._lib.radad_knn_add(self._h, x.data_ptr(), x.shape[0], _lib.stream_ptr(x.device)), "radad_knn_add")
 
-    def search_device(self, q, k: int):
+    def search_device(self, q, k: int, return_f64: bool = False):
+        """q [nq, d] CUDA tensor -> (D f32 [nq,k], I i64 [nq,k]) on the device; with return_f64 also the float64
+        distances the ranking was made on (used by the sharded merge)."""
         import torch
         _lib.require_cuda(q, "q")
         q = q.contiguous().float()
@@ -96,10 +98,12 @@ class HipFlatIndex:
             raise ValueError(f"search expects [nq, {self.d}], got {tuple(q.shape)}")
         D = torch.empty((q.shape[0], k), device=q.device, dtype=torch.float32)
         I = torch.empty((q.shape[0], k), device=q.device, dtype=torch.int64)
+        K64 = torch.empty((q.shape[0], k), device=q.device, dtype=torch.float64) if return_f64 else None
         with torch.cuda.device(q.device):
-            _lib.check(self._lib.radad_knn_search(self._h, q.data_ptr(), q.shape[0], int(k), D.data_ptr(), I.data_ptr(),
-                                                  _lib.stream_ptr(q.device)), "radad_knn_search")
-        return D, I
+            _lib.check(self._lib.radad_knn_search_f64(self._h, q.data_ptr(), q.shape[0], int(k), D.data_ptr(), I.data_ptr(),
+                                                      K64.data_ptr() if return_f64 else None, _lib.stream_ptr(q.device)),
+                       "radad_knn_search")
+        return (D, I, K64) if return_f64 else (D, I)
 
     def reconstruct_batch(self, idx):
         """idx: int64 CUDA tensor of any shape -> [*idx.shape, d]; negative ids give zero rows."""

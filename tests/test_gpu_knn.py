@@ -20,18 +20,16 @@ def _mk(gpu, metric, dim, id_base=0):
 
 def _check(D, I, od, oi, metric, unit):
     np.testing.assert_array_equal(I, oi)
-    if metric == "L2" and not unit:
-        np.testing.assert_allclose(D, od, rtol=1e-4, atol=1e-3)
+    if unit:
+        np.testing.assert_allclose(D, od, rtol=0, atol=1e-4)      # north_star: 1e-4 absolute on unit-norm data
     else:
-        np.testing.assert_allclose(D, od, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(D, od, rtol=1e-6, atol=1e-6)   # raw data: distances are float64 re-scored, so ~1 ulp
 
 
 def _assert_separated(od, D):
-    """'bit-exact ids' is only a fair demand where the fp64 gap between consecutive ranks exceeds the fp32 error;
-    the seeds used here keep every gap above 4x the error actually observed (otherwise: change the seed, not the test)"""
-    gaps = O.rank_gaps(od)
-    err = np.abs(D - od).max()
-    assert gaps.min() > 4 * err, f"seed gives near-ties (min gap {gaps.min():.3e} vs fp32 error {err:.3e}); pick another seed"
+    """the final order comes from a float64 re-rank, so ids must match the oracle whenever the oracle itself has no
+    exact tie between different rows (ties are covered by test_knn_ties_break_to_lower_id)"""
+    assert O.rank_gaps(od).min() > 0, "the seed produced an exact float64 tie; pick another seed"
 
 
 @pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
