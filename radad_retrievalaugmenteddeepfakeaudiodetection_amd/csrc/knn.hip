@@ -53,6 +53,93 @@ __device__ __forceinline__ bool better(float s, int i, float ws, int wi) {
     return s > ws || (s == ws && i < wi);
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// One 128 x 128 tile of S = Y . Q^T over the full depth: acc[mt][nt] (wave sub-tile 64 x 64 as 2 x 2 MFMA 32x32 blocks).
+// Global -> LDS staging uses buffer loads: the descriptors are wave-uniform (SGPRs), rows past the end of the
+// chunk / of the query block fall outside num_records and read as zero, and a thread needs only four 32-bit
+// offsets for all of its loads (the K step goes into the scalar offset).
+struct TileCtx {
+    int dim, nk;
+    unsigned voff[4];     // byte offset of (row ld_r + 32 i, col ld_c) inside a tile
+    int ld_r, ld_c;
+    int wm, wn, l31, lh;
+};
+
+__device__ __forceinline__ void knn_tile_gemm(const TileCtx& c, __amdgpu_buffer_rsrc_t ra_desc, __amdgpu_buffer_rsrc_t rq_desc,
+                                              float* sA, float* sB, f32x16 (&acc)[2][2]) {
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int kc) {
+        // columns past `dim` (last K step when dim % 32 != 0) must read as zero: push the OFFSET out of range rather
+        // than selecting on the loaded data -- a select would make the compiler wait for the loads right here
+        const bool kin = kc * KT_K + c.ld_c < c.dim;
+        const int soff = kc * KT_K * (int)sizeof(float);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned vo = kin ? c.voff[i] : 0x7FFF0000u;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_desc, vo, soff, 0));
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rq_desc, vo, soff, 0));
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = c.ld_r + 32 * i;
+            *reinterpret_cast<f32x4*>(sA + (buf * KT_M + r) * KT_LD + c.ld_c) = ra[i];
+            *reinterpret_cast<f32x4*>(sB + (buf * KT_N + r) * KT_LD + c.ld_c) = rb[i];
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kc = 0; kc < c.nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < c.nk) gload(kc + 1);
+        const float* a_base = sA + (buf * KT_M + c.wm * 64 + c.l31) * KT_LD + 4 * c.lh;
+        const float* b_base = sB + (buf * KT_N + c.wn * 64 + c.l31) * KT_LD + 4 * c.lh;
+#pragma unroll
+        for (int kk = 0; kk < KT_K / 8; ++kk) {
+            // lanes 0-31 hold k = 8kk+j, lanes 32-63 k = 8kk+4+j of their row: one ds_read_b128 feeds 4 MFMAs
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_base + kk * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_base + 32 * KT_LD + kk * 8);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b_base + kk * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(b_base + 32 * KT_LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (kc + 1 < c.nk) swrite(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ TileCtx make_tile_ctx(int dim, int tid) {
+    TileCtx c;
+    c.dim = dim;
+    c.nk = (dim + KT_K - 1) / KT_K;
+    c.ld_r = tid >> 3;
+    c.ld_c = (tid & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c.voff[i] = (unsigned)(((c.ld_r + 32 * i) * dim + c.ld_c) * (int)sizeof(float));
+    const int lane = tid & 63, wave = tid >> 6;
+    c.wm = wave & 1; c.wn = wave >> 1; c.l31 = lane & 31; c.lh = lane >> 5;
+    return c;
+}
+// descriptor over `rows` rows of `dim` floats starting at `base` (wave-uniform inputs only)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_desc(const float* base, int rows, int dim) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, rows * dim * (int)sizeof(float), 0x00020000);
+}
+
 __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32(KnnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sA = reinterpret_cast<float*>(smem);          // [2][KT_M][KT_LD]
@@ -79,7 +166,6 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32(KnnParams p) {
     const int q0 = qt * KT_N;
     const int64_t chunk_begin = (int64_t)split * p.chunk_rows;
     const int64_t chunk_end = min(chunk_begin + p.chunk_rows, p.n);
-    const int nk = (p.dim + KT_K - 1) / KT_K;
     const int k = p.k;
 
     // this block's output lists double as the running top-k lists (rarely touched; L2-resident)
@@ -94,68 +180,12 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32(KnnParams p) {
     }
     if (chunk_begin >= chunk_end) return;
 
-    // staging registers: 4 float4 of the store tile + 4 float4 of the query tile per thread
-    f32x4 ra[4], rb[4];
-    const int ld_r = tid >> 3;        // + 32*i
-    const int ld_c = (tid & 7) * 4;
+    const TileCtx tc = make_tile_ctx(p.dim, tid);
+    const __amdgpu_buffer_rsrc_t q_desc = rows_desc(p.q + (int64_t)q0 * p.dim, min(KT_N, p.nq - q0), p.dim);
 
     for (int64_t row0 = chunk_begin; row0 < chunk_end; row0 += KT_M) {
         f32x16 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-        auto gload = [&](int kc) {
-            const int kcol = kc * KT_K + ld_c;
-            const bool kin = kcol < p.dim;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = ld_r + 32 * i;
-                const int64_t row = row0 + r;
-                const int qrow = q0 + r;
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                ra[i] = (kin && row < chunk_end) ? *reinterpret_cast<const f32x4*>(p.db + row * p.dim + kcol) : z;
-                rb[i] = (kin && qrow < p.nq) ? *reinterpret_cast<const f32x4*>(p.q + (int64_t)qrow * p.dim + kcol) : z;
-            }
-        };
-        auto swrite = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = ld_r + 32 * i;
-                *reinterpret_cast<f32x4*>(sA + (buf * KT_M + r) * KT_LD + ld_c) = ra[i];
-                *reinterpret_cast<f32x4*>(sB + (buf * KT_N + r) * KT_LD + ld_c) = rb[i];
-            }
-        };
-
-        gload(0);
-        swrite(0);
-        __syncthreads();
-        for (int kc = 0; kc < nk; ++kc) {
-            const int buf = kc & 1;
-            if (kc + 1 < nk) gload(kc + 1);
-            const float* a_base = sA + (buf * KT_M + wm * 64 + l31) * KT_LD + 4 * lh;
-            const float* b_base = sB + (buf * KT_N + wn * 64 + l31) * KT_LD + 4 * lh;
-#pragma unroll
-            for (int kk = 0; kk < KT_K / 8; ++kk) {
-                // lanes 0-31 hold k = 8kk+j, lanes 32-63 k = 8kk+4+j of their row: one ds_read_b128 feeds 4 MFMAs
-                f32x4 a0 = *reinterpret_cast<const f32x4*>(a_base + kk * 8);
-                f32x4 a1 = *reinterpret_cast<const f32x4*>(a_base + 32 * KT_LD + kk * 8);
-                f32x4 b0 = *reinterpret_cast<const f32x4*>(b_base + kk * 8);
-                f32x4 b1 = *reinterpret_cast<const f32x4*>(b_base + 32 * KT_LD + kk * 8);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
-                }
-            }
-            if (kc + 1 < nk) swrite(buf ^ 1);
-            __syncthreads();
-        }
+        knn_tile_gemm(tc, rows_desc(p.db + row0 * p.dim, (int)min((int64_t)KT_M, chunk_end - row0), p.dim), q_desc, sA, sB, acc);
 
         // ---- fused top-k epilogue -------------------------------------------------------------
         // acc[mt][nt][r] = dot(store row row0 + wm*64 + mt*32 + (r&3) + 8*(r>>2) + 4*lh,
@@ -213,6 +243,174 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32(KnnParams p) {
         __syncthreads();
     }
 }
+
+// ---- scan kernel, register-list variant (k + margin <= KSEL) ---------------------------------------------------
+// Same MFMA main loop as k_knn_f32; the fused top-k differs:
+//   * thread t < 128 owns query q0+t and keeps its KSEL best (score, row) pairs in REGISTERS as 64-bit sortable
+//     keys (ordered-float score in the high word, ~row in the low word: one u64 compare == (score, -row) order);
+//     an insertion is a fully unrolled compare/select ladder -- no memory traffic, no pointer chasing.
+//   * every lane filters its 64 accumulators against its two queries' thresholds (LDS, 1 float each) and pushes the
+//     rare survivors into a per-query LDS slot buffer (CAND_CAP entries, ds_add_rtn for the slot);
+//   * a query that overflows its buffer in one tile (always the first tile of a chunk, or adversarially ordered
+//     data) takes the exact slow path: the whole 128x128 score tile is parked in LDS and its owner re-reads its row.
+constexpr int CAND_CAP = 8;
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 pack_key(float s, int id) {
+    unsigned u = __float_as_uint(s);
+    u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;
+    return ((u64)u << 32) | (u64)(0xFFFFFFFFu - (unsigned)id);
+}
+__device__ __forceinline__ float key_score(u64 k) {
+    unsigned u = (unsigned)(k >> 32);
+    u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ int key_id(u64 k) { return (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)); }
+
+template <int KSEL>
+__device__ __forceinline__ void list_insert(u64 (&l)[KSEL], u64 key) {
+    if (key <= l[KSEL - 1]) return;
+#pragma unroll
+    for (int j = KSEL - 1; j >= 1; --j) {
+        const bool up = key > l[j - 1];            // key ranks before entry j-1: that entry moves down to j
+        const bool here = !up && key > l[j];       // key lands at j
+        l[j] = up ? l[j - 1] : (here ? key : l[j]);
+    }
+    l[0] = key > l[0] ? key : l[0];
+}
+
+template <int KSEL>
+__global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sA = reinterpret_cast<float*>(smem);          // [2][KT_M][KT_LD]
+    float* sB = sA + 2 * KT_M * KT_LD;                   // [2][KT_N][KT_LD]
+    float* s_thr = sB + 2 * KT_N * KT_LD;                // [KT_N] current KSEL-th best score of each query
+    int* s_cnt = reinterpret_cast<int*>(s_thr + KT_N);   // [KT_N] candidates pushed this tile
+    float2* s_cand = reinterpret_cast<float2*>(sA);      // [KT_N][CAND_CAP] (score, row bits); aliases the tiles (epilogue only)
+    float* sS = sA;                                      // [KT_N][KS_LD] score tile of the overflow path (aliases too)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int bid = blockIdx.x;              // XCD-aware mapping: see k_knn_f32
+    const int xcd = bid & 7;
+    const int slot_b = bid >> 3;
+    const int qt = slot_b % p.n_qtiles;
+    const int split = (slot_b / p.n_qtiles) * 8 + xcd;
+
+    const int q0 = qt * KT_N;
+    const int64_t chunk_begin = (int64_t)split * p.chunk_rows;
+    const int64_t chunk_end = min(chunk_begin + p.chunk_rows, p.n);
+    const bool owner = tid < KT_N && q0 + tid < p.nq;
+
+    const u64 SENT = pack_key(-INFINITY, IDX_SENTINEL);
+    u64 lst[KSEL];
+#pragma unroll
+    for (int j = 0; j < KSEL; ++j) lst[j] = SENT;
+    if (tid < KT_N) { s_thr[tid] = -INFINITY; s_cnt[tid] = 0; }
+    __syncthreads();
+
+    const TileCtx tc = make_tile_ctx(p.dim, tid);
+    const __amdgpu_buffer_rsrc_t q_desc = rows_desc(p.q + (int64_t)q0 * p.dim, min(KT_N, p.nq - q0), p.dim);
+    const int ql[2] = {wn * 64 + l31, wn * 64 + 32 + l31};
+    const bool qvalid[2] = {q0 + ql[0] < p.nq, q0 + ql[1] < p.nq};
+
+    for (int64_t row0 = chunk_begin; row0 < chunk_end; row0 += KT_M) {
+        f32x16 acc[2][2];
+        knn_tile_gemm(tc, rows_desc(p.db + row0 * p.dim, (int)min((int64_t)KT_M, chunk_end - row0), p.dim), q_desc, sA, sB, acc);
+
+        // ---- fused top-k epilogue -------------------------------------------------------------------------
+        const int rowlimit = (int)min((int64_t)KT_M, chunk_end - row0);
+        if (p.l2) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float yn = p.ynorm[min(row0 + rl, p.n - 1)];
+                    acc[mt][0][r] = 2.f * acc[mt][0][r] - yn;
+                    acc[mt][1][r] = 2.f * acc[mt][1][r] - yn;
+                }
+        }
+        // phase 1: every lane filters its 2 x 32 scores and pushes survivors to its queries' slot buffers
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float thr = s_thr[ql[nt]];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float gm = acc[mt][nt][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) gm = fmaxf(gm, acc[mt][nt][r]);
+                if (qvalid[nt] && gm >= thr) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (rl < rowlimit && acc[mt][nt][r] >= thr) {
+                            const int sl = atomicAdd(&s_cnt[ql[nt]], 1);
+                            if (sl < CAND_CAP)
+                                s_cand[ql[nt] * CAND_CAP + sl] = make_float2(acc[mt][nt][r], __int_as_float((int)(row0 + rl)));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // phase 2: owners drain their buffers into the register lists
+        bool over = false;
+        if (tid < KT_N) {
+            const int c = s_cnt[tid];
+            over = owner && c > CAND_CAP;
+            if (owner && !over && c > 0) {
+                for (int i = 0; i < c; ++i) {
+                    const float2 cv = s_cand[tid * CAND_CAP + i];
+                    list_insert<KSEL>(lst, pack_key(cv.x, __float_as_int(cv.y)));
+                }
+                s_thr[tid] = key_score(lst[KSEL - 1]);
+            }
+            s_cnt[tid] = 0;
+        }
+        if (__syncthreads_or(over ? 1 : 0)) {
+            // overflow path (exact, slower): park the score tile query-major and let the owners re-read their rows
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int rl = wm * 64 + mt * 32 + 8 * g + 4 * lh;
+                    f32x4 v0, v1;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v0[i] = acc[mt][0][4 * g + i]; v1[i] = acc[mt][1][4 * g + i]; }
+                    *reinterpret_cast<f32x4*>(sS + (wn * 64 + l31) * KS_LD + rl) = v0;
+                    *reinterpret_cast<f32x4*>(sS + (wn * 64 + 32 + l31) * KS_LD + rl) = v1;
+                }
+            __syncthreads();
+            if (over) {
+                const float* srow = sS + tid * KS_LD;
+                for (int c = 0; c < rowlimit; c += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + c);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (c + i < rowlimit) list_insert<KSEL>(lst, pack_key(v[i], (int)(row0 + c + i)));
+                }
+                s_thr[tid] = key_score(lst[KSEL - 1]);
+            }
+            __syncthreads();
+        }
+    }
+    // the lists leave the registers once, at the end of the chunk
+    if (owner) {
+        float* ls = p.part_score + ((int64_t)(q0 + tid) * p.n_splits + split) * p.k;
+        int* li = p.part_idx + ((int64_t)(q0 + tid) * p.n_splits + split) * p.k;
+#pragma unroll
+        for (int j = 0; j < KSEL; ++j)
+            if (j < p.k) { ls[j] = key_score(lst[j]); li[j] = key_id(lst[j]); }
+    }
+}
+
+constexpr size_t knn_reg_lds_bytes() { return sizeof(float) * (2 * KT_M * KT_LD + 2 * KT_N * KT_LD + KT_N) + sizeof(int) * KT_N; }
 
 // ---- merge of sorted partial lists -----------------------------------------------------------------------
 // element (part, q, j) of a list sits at [part*sp + q*sq + j]; lists are sorted best-first and padded with
@@ -655,13 +853,28 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     p.db = h->rows; p.ynorm = h->ynorm; p.q = q_use; p.n = h->ntotal; p.nq = (int)nq; p.dim = h->dim; p.k = ksel;
     p.l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0;
     p.n_qtiles = n_qtiles; p.n_splits = n_splits; p.chunk_rows = chunk_rows; p.part_score = ps; p.part_idx = pi;
-    // 73 728 B of dynamic LDS > the 64 KB default: raise the limit (per device, so on every call)
-    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes());
-    RADAD_HIP_CHECK(attr);
-    h->prof.begin(st);
-    hipLaunchKernelGGL(k_knn_f32, dim3((unsigned)(n_qtiles * n_splits)), dim3(KNN_THREADS), knn_lds_bytes(), st, p);
-    h->prof.end(st);
+    // > 64 KB of dynamic LDS: raise the limit (per device, so on every call).  Lists live in registers when
+    // k + margin fits 16 or 32 entries (k <= 26), otherwise in the partial-result arrays (generic kernel).
+    const dim3 grid((unsigned)(n_qtiles * n_splits));
+    if (ksel <= 16) {
+        RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32_reg<16>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_reg_lds_bytes()));
+        h->prof.begin(st);
+        hipLaunchKernelGGL(k_knn_f32_reg<16>, grid, dim3(KNN_THREADS), knn_reg_lds_bytes(), st, p);
+        h->prof.end(st);
+    } else if (ksel <= 32) {
+        RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32_reg<32>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_reg_lds_bytes()));
+        h->prof.begin(st);
+        hipLaunchKernelGGL(k_knn_f32_reg<32>, grid, dim3(KNN_THREADS), knn_reg_lds_bytes(), st, p);
+        h->prof.end(st);
+    } else {
+        RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes()));
+        h->prof.begin(st);
+        hipLaunchKernelGGL(k_knn_f32, grid, dim3(KNN_THREADS), knn_lds_bytes(), st, p);
+        h->prof.end(st);
+    }
     RADAD_HIP_CHECK(hipGetLastError());
 
     RefineParams m;
