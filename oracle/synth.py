@@ -28,7 +28,7 @@ def _splitmix64(x):
 def _hash(seed, row, col):
     """64-bit hash of (seed,row,col); row/col are uint64 arrays (broadcast)."""
     with np.errstate(over="ignore"):
-        r = _splitmix64(row.astype(np.uint64) ^ np.uint64(seed))
+        r = _splitmix64(row.astype(np.uint64) ^ _splitmix64(np.uint64(seed)))   # seed is hashed first: streams do not alias
         return _splitmix64(r ^ (col.astype(np.uint64) * np.uint64(0x100000001B3)))
 
 

@@ -16,7 +16,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     return z ^ (z >> 31);
 }
 __device__ __forceinline__ uint64_t hash3(uint64_t seed, uint64_t row, uint64_t col) {
-    const uint64_t r = splitmix64(row ^ seed);
+    const uint64_t r = splitmix64(row ^ splitmix64(seed));   // seed is hashed first: streams do not alias
     return splitmix64(r ^ (col * 0x100000001B3ull));
 }
 __device__ __forceinline__ int ih4(uint64_t h) {

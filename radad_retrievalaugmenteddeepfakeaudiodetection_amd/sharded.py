@@ -83,10 +83,12 @@ class ShardedSearch:
         if self.world == 1:
             return d_loc.float(), i_loc
         Q = q_all.shape[0]
-        d_all = torch.empty((self.world, Q, k), device=d_loc.device, dtype=d_loc.dtype)
-        i_all = torch.empty((self.world, Q, k), device=i_loc.device, dtype=i_loc.dtype)
+        # concatenated output form (accepted by both RCCL and gloo), viewed as [G, Q, k]
+        d_all = torch.empty((self.world * Q, k), device=d_loc.device, dtype=d_loc.dtype)
+        i_all = torch.empty((self.world * Q, k), device=i_loc.device, dtype=i_loc.dtype)
         dist.all_gather_into_tensor(d_all, d_loc.contiguous(), group=self.group)
         dist.all_gather_into_tensor(i_all, i_loc.contiguous(), group=self.group)
+        d_all, i_all = d_all.view(self.world, Q, k), i_all.view(self.world, Q, k)
         if return_all:
             return self.merge(self.metric, d_all, i_all, k)
         qr = q_local.shape[0]

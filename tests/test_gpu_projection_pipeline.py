@@ -1,0 +1,165 @@
+"""GPU parity: ProjectionLayer forward vs the reference golden vectors, and the two hot pipeline methods
+(process_audio_batch / retrieve_similar_vectors) vs the oracle restatement of pipeline.py:392-414,449-532."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import radad_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _proj_shapes(D, H=256, Oo=128):
+    return {"attention_score.weight": (H, D), "attention_score.bias": (H,), "attention_final.weight": (1, H),
+            "attention_final.bias": (1,), "cst_hidden.weight": (H, D), "cst_hidden.bias": (H,),
+            "cst_output.weight": (D, H), "cst_output.bias": (D,), "weight_sum.weight": (H, D), "weight_sum.bias": (H,),
+            "normalization.weight": (H,), "normalization.bias": (H,), "unified_embedding.weight": (Oo, H),
+            "unified_embedding.bias": (Oo,)}
+
+
+@pytest.mark.parametrize("D", [512, 3584])
+def test_projection_matches_reference_golden(gpu, golden_dir, D):
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    g = np.load(os.path.join(golden_dir, "projection.npz"))
+    cfg = R.Config()
+    cfg.update(device=gpu)
+    layer = R.ProjectionLayer(cfg, D).eval()
+    sd = synth.fill_state_dict(_proj_shapes(D), int(g[f"proj{D}_seed"]))
+    layer.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})         # the reference's own key names
+    with torch.no_grad():
+        y = layer(torch.from_numpy(g[f"proj{D}_x"]).to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(y, g[f"proj{D}_y"], rtol=0, atol=1e-4)               # vs the reference module's output
+    np.testing.assert_allclose(y, O.projection_forward(g[f"proj{D}_x"], sd), rtol=0, atol=1e-4)
+    # a batch that is not a multiple of any tile, and forward_batch (projection.py:119-122)
+    x = torch.from_numpy(synth.rows(0, 37 * 5, D, 77).reshape(37, 5, D)).to(gpu)
+    with torch.no_grad():
+        y2 = layer(x).cpu().numpy()
+        y3 = layer.forward_batch([x[i] for i in range(37)]).cpu().numpy()
+    np.testing.assert_allclose(y2, O.projection_forward(x.cpu().numpy(), sd), rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(y2, y3)
+    layer.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        layer(x)
+
+
+class _FakeDataset:
+    """what process_audio_batch needs from AudioDataset: load_audio(path) -> float32 [N] (dataset.py:139-153)"""
+
+    def __init__(self, clips):
+        self.clips = clips
+
+    def load_audio(self, path):
+        return self.clips.get(path)
+
+
+def test_process_audio_batch_and_retrieve(gpu, tmp_path):
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    cfg = R.Config()
+    cfg.update(device=gpu, feature_dim=64, tpp_levels=[1, 2, 4], top_k=3, vector_db_index_type="L2",
+               vector_db_path=str(tmp_path / "vdb"))
+    pipe = R.HotPathPipeline(cfg)
+    D = pipe.tpp.get_output_dim()
+    assert D == 7 * 64
+    # ---- empty store: zeros / NaN with all four arities (pipeline.py:465-476)
+    q0 = torch.zeros(2, D, device=gpu)
+    v, l = pipe.retrieve_similar_vectors(q0)
+    assert v.shape == (2, 3, D) and l.shape == (2, 3) and float(v.abs().sum()) == 0
+    v, l, p, d = pipe.retrieve_similar_vectors(q0, return_info=True, return_distances=True)
+    assert p == [["", "", ""], ["", "", ""]] and bool(torch.isnan(d).all())
+    assert len(pipe.retrieve_similar_vectors(q0, return_info=True)) == 3
+    assert len(pipe.retrieve_similar_vectors(q0, return_distances=True)) == 3
+
+    # ---- segment + embed through the reference's signature
+    lens = [48000, 48000, 64000, 20000, 70001, 48000]          # the reference's 3.0 s clips, plus ragged ones
+    wav = synth.audio(0, len(lens), max(lens), 1234)
+    clips = {f"/data/set/clip{i}.wav": wav[i, :n] for i, n in enumerate(lens)}
+    ds = _FakeDataset(clips)
+    paths = list(clips)
+    emb = pipe.process_audio_batch(paths, ds)
+    assert emb.shape == (len(lens), D) and emb.is_cuda
+    fe = pipe.feature_extractor
+    ref = O.embed_clips([clips[p] for p in paths], 32000, 16000, fe.proj_w, fe.proj_b, (1, 2, 4), "max")
+    np.testing.assert_allclose(emb.cpu().numpy(), ref, rtol=0, atol=1e-4)
+    with pytest.raises(RuntimeError, match="Failed to load"):
+        pipe.process_audio_batch(["/nope.wav"], ds)              # pipeline.py:398-399
+
+    # ---- build a store that contains the queries themselves (same basenames) plus distractors
+    emb_h = emb.cpu().numpy()
+    noise = synth.rows(0, 200, D, 5) * np.float32(0.01 * np.abs(emb_h).mean())
+    db = np.concatenate([emb_h, emb_h[np.arange(200) % len(lens)] + noise]).astype(np.float32)
+    db_paths = [f"/train/clip{i}.wav" for i in range(len(lens))] + [f"/train/other{i}.wav" for i in range(200)]
+    labels = [float(i % 2) for i in range(len(db))]
+    pipe.vector_db.add_vectors(db, db_paths, labels, {"speaker_id": ["s"] * len(db)})
+    K = cfg.top_k
+    for exclude_self in (True, False):
+        vec, lbl, rp, dist = pipe.retrieve_similar_vectors(emb, query_paths=paths, exclude_self=exclude_self,
+                                                           return_info=True, return_distances=True)
+        k_search = K + (10 if exclude_self else 0)                                    # pipeline.py:478
+        od, oi = O.knn(db, emb_h, k_search, "L2")
+        ov, ol, op, odist = O.retrieve_postprocess(od, oi, db, db_paths, labels, K, D, query_paths=paths,
+                                                   exclude_self=exclude_self)
+        assert rp == op
+        np.testing.assert_array_equal(lbl.cpu().numpy(), ol)
+        np.testing.assert_allclose(dist.cpu().numpy(), odist, rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(vec.cpu().numpy(), ov)                           # the STORED rows, bit for bit
+        if exclude_self:   # every clipN.wav of the batch is excluded from every row (pipeline.py:463,497-499)
+            assert all(os.path.basename(x).startswith("other") for row in rp for x in row)
+        else:
+            assert [row[0] for row in rp] == [f"/train/clip{i}.wav" for i in range(len(lens))]
+    # no query paths: exclusion by training_file_ids (pipeline.py:500-502); too few survivors -> padding (:511-515)
+    pipe.training_file_ids = {os.path.basename(p) for p in db_paths[:-2]}
+    vec, lbl, rp, dist = pipe.retrieve_similar_vectors(emb[:1], return_info=True, return_distances=True)
+    assert all(x == "" or os.path.basename(x) in ("other198.wav", "other199.wav") for x in rp[0])
+    n_real = sum(1 for x in rp[0] if x)
+    assert bool(torch.isnan(dist[0, n_real:]).all()) and float(vec[0, n_real:].abs().sum()) == 0
+
+
+def test_full_size_properties(gpu, knn_oracle_lib):
+    """BASELINE-sized store (1M x 512, cosine, k=10): size-independent properties + a C-oracle check on a query sample"""
+    import torch
+    from conftest import c_knn
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import hip_merge, shard_bounds
+    lib = _lib.load()
+    n, dim, k, nq = 1_000_000, 512, 10, 256
+    rows = torch.empty((n, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(rows.data_ptr(), 0, n, dim, 4321, gpu.index or 0, _lib.stream_ptr(gpu)))
+    q = torch.empty((nq, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(q.data_ptr(), 0, nq, dim, 977, gpu.index or 0, _lib.stream_ptr(gpu)))
+    rows[(torch.arange(nq, device=gpu) * 3907 + 11) % n] = q + 0.05 * rows[:nq]        # one planted neighbour per query
+    idx = HipFlatIndex(dim, _lib.METRIC_COSINE, gpu.index or 0)
+    idx.add_device(rows)
+    D, I, K64 = idx.search_device(q, k, return_f64=True)
+    # sortedness, id range/uniqueness, planted neighbour first
+    assert bool((D[:, :-1] >= D[:, 1:]).all()) and bool((I >= 0).all()) and bool((I < n).all())
+    assert all(len(set(r)) == k for r in I.cpu().tolist())
+    assert bool((I[:, 0] == (torch.arange(nq, device=gpu) * 3907 + 11) % n).all())
+    # distances equal float64 inner products of the stored rows (reconstruct) with the normalised queries
+    qn = torch.empty_like(q)
+    _lib.check(lib.radad_rownorm(q.data_ptr(), qn.data_ptr(), nq, dim, gpu.index or 0, _lib.stream_ptr(gpu)))
+    rec = idx.reconstruct_batch(I)
+    ip = (rec.double() * qn.double()[:, None, :]).sum(-1)
+    assert float((ip - K64).abs().max()) < 1e-12 and float((ip.float() - D).abs().max()) < 1e-6
+    # idempotence and shard-merge invariance: 4 shards with global ids, merged on the float64 keys
+    D2, I2 = idx.search_device(q, k)
+    assert torch.equal(I, I2) and torch.equal(D, D2)
+    pd, pi = [], []
+    for r in range(4):
+        lo, hi = shard_bounds(n, 4, r)
+        sh = HipFlatIndex(dim, _lib.METRIC_COSINE, gpu.index or 0, id_base=lo)
+        sh.add_device(rows[lo:hi])
+        _, i_, k_ = sh.search_device(q, k, return_f64=True)
+        pd.append(k_); pi.append(i_)
+        del sh
+    md, mi = hip_merge(_lib.METRIC_COSINE, torch.stack(pd), torch.stack(pi), k)
+    assert torch.equal(mi, I) and torch.equal(md, D)
+    # C oracle (float64, OpenMP) on a 32-query sample against the rows AS STORED
+    stored = torch.empty_like(rows)
+    _lib.check(lib.radad_rownorm(rows.data_ptr(), stored.data_ptr(), n, dim, gpu.index or 0, _lib.stream_ptr(gpu)))
+    od, oi = c_knn(knn_oracle_lib, stored.cpu().numpy(), qn[:32].cpu().numpy(), k, "IP")
+    np.testing.assert_array_equal(I[:32].cpu().numpy(), oi)
+    np.testing.assert_allclose(K64[:32].cpu().numpy(), od, rtol=0, atol=1e-12)

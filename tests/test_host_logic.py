@@ -1,0 +1,168 @@
+"""CPU: the host-side mirror (no GPU): segmenter vs the reference golden vectors, mel filter bank, config, shard
+bounds, and the C-ABI library: loads, exports every symbol include/radad_hip.h declares, argument errors surface as
+the reference's exception types.  No compute entry point is called (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+from radad_retrievalaugmenteddeepfakeaudiodetection_amd.feature_extractor import mel_filter_bank_slaney, synthetic_projection
+from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import shard_bounds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg():
+    import torch
+    c = R.Config()
+    c.device = torch.device("cpu")
+    return c
+
+
+def _ramp(n):
+    return (np.arange(n, dtype=np.float32) % 977) / np.float32(977.0) - np.float32(0.5)
+
+
+def test_header_symbols_are_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "radad_hip.h")).read()
+    declared = set(re.findall(r"\b(radad_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"radad_embed_cfg", "radad_proj_weights"}
+    assert declared == set(_lib.SIGNATURES), f"header vs binding mismatch: {declared ^ set(_lib.SIGNATURES)}"
+    lib = _lib.load()                      # getattr on every declared name: raises if the .so lacks one
+    assert lib.radad_abi_version() == 1
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name)
+
+
+def test_library_is_the_in_tree_hip_build():
+    assert os.path.dirname(_lib.LIB_PATH) == os.path.join(ROOT, "radad_retrievalaugmenteddeepfakeaudiodetection_amd")
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_knn_f32" in blob and b"k_logmel" in blob    # device code objects are embedded
+
+
+def test_abi_argument_errors_without_gpu():
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.radad_knn_create(30, 0, 0, 0, C.byref(h)) == _lib.RADAD_EINVAL         # dim % 4
+    assert b"multiple of 4" in lib.radad_last_error()
+    assert lib.radad_knn_create(32, 7, 0, 0, C.byref(h)) == _lib.RADAD_EINVAL         # metric
+    with pytest.raises(ValueError):
+        _lib.check(lib.radad_knn_create(32, 7, 0, 0, C.byref(h)))
+    assert lib.radad_knn_search(None, None, 1, 1, None, None, None) == _lib.RADAD_EINVAL
+    assert lib.radad_topk_merge(0, None, None, 0, 1, 1, None, None, 0, None) == _lib.RADAD_EINVAL
+    assert lib.radad_projection_workspace_bytes(4, 5, 512, 256, 128) > 0
+    assert lib.radad_projection_workspace_bytes(-1, 5, 512, 256, 128) == -1
+
+
+def test_segment_count_c_equals_python_rule(golden_dir):
+    lib = _lib.load()
+    g = np.load(os.path.join(golden_dir, "segmenter.npz"))
+    for n in list(g["lengths"]) + [0, 1, 15999, 16000, 16001, 95999, 96000, 10 ** 7]:
+        n = int(n)
+        assert lib.radad_segment_count(n, 32000, 16000) == max(1, (n - 32000) // 16000 + 1)
+    for n in g["lengths"]:
+        assert lib.radad_segment_count(int(n), 32000, 16000) == int(g[f"n{int(n)}_count"])
+    assert lib.radad_segment_count(10, 0, 5) == -1
+
+
+def test_audio_segmenter_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "segmenter.npz"))
+    seg = R.AudioSegmenter(_cfg())
+    assert (seg.segment_length, seg.hop_length) == (int(g["segment_length"]), int(g["hop_length"]))
+    for n in g["lengths"]:
+        n = int(n)
+        segs = seg.segment_audio(_ramp(n))
+        assert len(segs) == int(g[f"n{n}_count"]) == seg.num_segments(n)
+        assert str(segs[-1].dtype) == str(g[f"n{n}_dtype"])
+        np.testing.assert_array_equal(np.stack([np.asarray(s[:8], np.float64) for s in segs]), g[f"n{n}_first8"])
+        np.testing.assert_array_equal(np.stack([np.asarray(s[-8:], np.float64) for s in segs]), g[f"n{n}_last8"])
+        np.testing.assert_array_equal(np.asarray([np.asarray(s, np.float64).sum() for s in segs]), g[f"n{n}_sum"])
+    with pytest.raises(ValueError, match="Expected 1D audio array"):
+        seg.segment_audio(np.zeros((2, 5), np.float32))
+    # unpadded segments are views of the input, as in the reference
+    a = _ramp(64000)
+    assert np.shares_memory(seg.segment_audio(a)[1], a)
+
+
+def test_segment_plan_is_the_csr_of_segment_audio():
+    seg = R.AudioSegmenter(_cfg())
+    lens = [100, 32000, 50000, 64000, 80001]
+    offs, start, valid, clip_seg = seg.plan(lens)
+    assert offs.tolist() == np.concatenate([[0], np.cumsum(lens)]).tolist()
+    assert clip_seg.tolist() == np.concatenate([[0], np.cumsum([seg.num_segments(n) for n in lens])]).tolist()
+    flat = np.concatenate([_ramp(n) for n in lens])
+    for b, n in enumerate(lens):
+        for j, s in enumerate(seg.segment_audio(_ramp(n))):
+            i = clip_seg[b] + j
+            np.testing.assert_array_equal(np.asarray(s[:valid[i]], np.float32), flat[start[i]:start[i] + valid[i]])
+
+
+def test_mel_filter_bank_matches_hf(golden_dir):
+    g = np.load(os.path.join(golden_dir, "frontend.npz"))
+    np.testing.assert_allclose(mel_filter_bank_slaney(), g["mel_filters"], rtol=1e-12, atol=1e-15)
+
+
+def test_config_and_selector():
+    c = _cfg()
+    assert (c.sample_rate, c.segment_length, c.segment_overlap, c.tpp_levels, c.tpp_pooling_type) == (16000, 2.0, 0.5, [1, 2, 4], "max")
+    assert (c.vector_db_index_type, c.top_k, c.projection_hidden_dim, c.projection_output_dim) == ("L2", 5, 256, 128)
+    c.update(top_k=7)
+    assert c.top_k == 7
+    with pytest.raises(ValueError, match="Invalid configuration parameter"):
+        c.update(nope=1)
+    c.feature_extractor_type = "bogus"
+    with pytest.raises(ValueError):
+        R.build_feature_extractor(c)
+    c.feature_extractor_type = "wav2vec2"
+    with pytest.raises(NotImplementedError):
+        R.build_feature_extractor(c)
+    c.feature_extractor_type = "melproj"
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        R.build_feature_extractor(c)              # device is cpu: the product path refuses, it does not fall back
+
+
+def test_no_cpu_fallback_in_operators():
+    import torch
+    c = _cfg()
+    c.feature_dim = 8
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        R.TemporalPyramidPooling(c).pool_features(torch.zeros(4, 8))
+    p = R.ProjectionLayer(c, 16).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"), torch.no_grad():
+        p(torch.zeros(1, 5, 16))
+    # parameter names/shapes equal the reference's fused layout, so its state_dict loads unchanged
+    sd = {k: tuple(v.shape) for k, v in p.state_dict().items()}
+    assert sd == {"attention_score.weight": (256, 16), "attention_score.bias": (256,), "attention_final.weight": (1, 256),
+                  "attention_final.bias": (1,), "cst_hidden.weight": (256, 16), "cst_hidden.bias": (256,),
+                  "cst_output.weight": (16, 256), "cst_output.bias": (16,), "weight_sum.weight": (256, 16),
+                  "weight_sum.bias": (256,), "normalization.weight": (256,), "normalization.bias": (256,),
+                  "unified_embedding.weight": (128, 256), "unified_embedding.bias": (128,)}
+
+
+def test_shard_bounds_partition():
+    for n, w in ((10, 3), (1_000_000, 8), (7, 8), (0, 2)):
+        b = [shard_bounds(n, w, r) for r in range(w)]
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+def test_synthetic_projection_is_deterministic():
+    w1, b1 = synthetic_projection(64, 5)
+    w2, b2 = synthetic_projection(64, 5)
+    np.testing.assert_array_equal(w1, w2)
+    assert w1.shape == (80, 64) and b1.shape == (64,) and w1.dtype == np.float32
+
+
+def test_oracle_is_not_imported_by_the_product():
+    pkg = os.path.join(ROOT, "radad_retrievalaugmenteddeepfakeaudiodetection_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace("oracle/synth.py", ""), f
