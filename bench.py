@@ -57,11 +57,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # RADAD_BENCH_REHEARSE=1: rehearse the N-rank code path on ONE GPU (all ranks on cuda:0, gloo collectives staged
+    # through the host).  Never used for a reported number.
+    rehearse = os.environ.get("RADAD_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
     from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
@@ -80,11 +88,8 @@ def main():
     _lib.check(lib.radad_synth_audio(wave.data_ptr(), rank * B, B, CLIP_SAMPLES, AUDIO_SEED, local_rank, _lib.stream_ptr(dev)))
     offsets = np.arange(B + 1, dtype=np.int64) * CLIP_SAMPLES
     emb0 = fe.embed_clips(wave, offsets)                              # also the first warm-up of the embed kernels
-    if world > 1:
-        all_emb = torch.empty((world * B, DIM), device=dev)
-        dist.all_gather_into_tensor(all_emb, emb0)
-    else:
-        all_emb = emb0
+    gather = ShardedSearch(None, 0)._all_gather
+    all_emb = gather(emb0) if world > 1 else emb0
     rows = torch.empty((hi - lo, DIM), device=dev, dtype=torch.float32)
     _lib.check(lib.radad_synth_rows(rows.data_ptr(), lo, hi - lo, DIM, DB_SEED, local_rank, _lib.stream_ptr(dev)))
     # plant two near-duplicates of every query so that the top of each list is known and non-trivial
@@ -134,7 +139,7 @@ def main():
     fe.profile(False)
     vdb.index.profile(False)
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -142,6 +147,10 @@ def main():
     mine = torch.arange(rank * B, (rank + 1) * B, device=dev)
     want0 = (mine * 977 + 17) % n_total
     planted_ok = bool((I[:, 0] == want0).all().item())
+    if world > 1:                                   # rank 0 reports the verdict of ALL ranks
+        t = torch.tensor([1.0 if planted_ok else 0.0], dtype=torch.float64, device="cpu" if rehearse else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        planted_ok = bool(t.item() > 0.5)
 
     ms_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt

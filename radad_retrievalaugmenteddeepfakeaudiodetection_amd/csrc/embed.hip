@@ -22,6 +22,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -79,6 +80,7 @@ struct LogmelParams {
     float* logmel;               // [S][nf][80] log10(max(mel,1e-10))  (before the max-8 clamp)
     float* seg_max;              // [S] max over the segment (pre-initialised)
     float* norm_out;             // optional [S][L]: the normalised segment (stage parity); nullptr otherwise
+    int debug;                   // timing experiments only (RADAD_DEBUG_LOGMEL): 1 = skip the MFMA loop, 2 = skip the prologue
 };
 
 __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
@@ -98,11 +100,38 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
     const int valid = p.seg_valid[s];
 
     // ---- stage the segment: raw -> stats -> normalise in place -> reflect borders ---------------------
+    // 16-byte loads, all of a thread's loads in flight before the first LDS write (the HBM latency is paid once)
     float lsum = 0.f;
-    for (int i = tid; i < L; i += LM_THREADS) {
-        const float v = i < valid ? src[i] : 0.f;
-        sig[sig_pos(i + 200)] = v;
-        lsum += v;
+    if ((p.debug & 2) == 0) {
+        const int nv = L >> 2;                                  // L % 160 == 0
+        const bool vec_ok = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+        constexpr int UNR = 6;
+        for (int b0 = 0; b0 < nv; b0 += LM_THREADS * UNR) {
+            f32x4 v[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i4 = b0 + u * LM_THREADS + tid;
+                const int i = i4 * 4;
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+                if (i4 < nv) {
+                    if (vec_ok && i + 4 <= valid) t = *reinterpret_cast<const f32x4*>(src + i);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = i + e < valid ? src[i + e] : 0.f;
+                    }
+                }
+                v[u] = t;
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int i4 = b0 + u * LM_THREADS + tid;
+                if (i4 < nv) {
+                    float* d = sig + sig_pos(i4 * 4 + 200);     // 4 | 200 and 4 | 160: the four samples share one 160-block
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { d[e] = v[u][e]; lsum += v[u][e]; }
+                }
+            }
+        }
     }
     float mean = 0.f, sd = 1.f;
     if (p.normalize) {
@@ -114,9 +143,10 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
         }
         const float var = block_sum(lsq, scratch, LM_WAVES) / (float)L;
         sd = sqrtf(var + 1e-7f);
+        const float inv = 1.0f / sd;
         for (int i = tid; i < L; i += LM_THREADS) {
             const int ps = sig_pos(i + 200);
-            const float v = (sig[ps] - mean) / sd;
+            const float v = (sig[ps] - mean) * inv;
             sig[ps] = v;
             if (p.norm_out) p.norm_out[(int64_t)s * L + i] = v;
         }
@@ -144,7 +174,11 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
     __syncthreads();
 
     const int t = min(wave * 32 + l31, p.nf - 1);      // this lane's frame (clamped: extra lanes recompute the last one)
-    const int tbase = FFT_HOP * t;
+    // LDS position of sample n of frame t: P(160t + n) = 161t + n + n/160.  With n = 40ch + 8kq + 4lh + j + 1 the
+    // quotient is constant inside a chunk (ch) except for ONE tap (n = 160: ch 3, kq 4, j 3, upper half-wave), so every
+    // read below is `per-chunk base + immediate`: no per-tap address arithmetic.
+    const int pb1 = 161 * t + 4 * lh;                 // + 40ch + [ch == 4]                      -> x[n]
+    const int pb2 = 161 * t - 4 * lh + 400 - 40;      // - 40ch + (ch <= 1 ? 2 : 1)              -> x[400 - n]
     f32x16 zacc[NMT];
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
@@ -152,7 +186,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
         for (int r = 0; r < 16; ++r) zacc[m][r] = 0.f;
 
     int step = 0;   // global chunk counter (bt*NCH + ch)
-    for (int bt = 0; bt < NBT; ++bt) {
+    for (int bt = 0; bt < ((p.debug & 1) ? 0 : NBT); ++bt) {
         f32x16 re, im;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { re[r] = 0.f; im[r] = 0.f; }
@@ -167,16 +201,18 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
                 if (tid + LM_THREADS < CHUNK_FLOATS / 4) pre[1] = nsrc[tid + LM_THREADS];
             }
             const float* cb = sbas + buf * CHUNK_FLOATS;
+            const float* p1 = sig + (pb1 + 40 * ch + (ch == 4 ? 1 : 0));
+            const float* p2 = sig + (pb2 - 40 * ch + (ch <= 1 ? 2 : 1));
+            const float* p1s = p1 + ((ch == 3) ? lh : 0);      // the one tap that crosses n = 160
 #pragma unroll
             for (int kq = 0; kq < KCH; ++kq) {
                 const f32x4 bc = *reinterpret_cast<const f32x4*>(cb + (kq * 2 + 0) * 256 + lane * 4);
                 const f32x4 bs = *reinterpret_cast<const f32x4*>(cb + (kq * 2 + 1) * 256 + lane * 4);
-                const int n0 = 8 * (ch * KCH + kq) + 4 * lh + 1;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int n = n0 + j;
-                    const float x1 = sig[sig_pos(tbase + n)];
-                    const float x2 = sig[sig_pos(tbase + N_FFT - n)];
+                    const int o = 8 * kq + j + 1;               // compile-time
+                    const float x1 = (kq == 4 && j == 3) ? p1s[o] : p1[o];
+                    const float x2 = p2[40 - o];
                     re = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[j], x1 + x2, re, 0, 0, 0);
                     im = __builtin_amdgcn_mfma_f32_32x32x2f32(bs[j], x1 - x2, im, 0, 0, 0);
                 }
@@ -555,6 +591,8 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.seg_len = h->cfg.segment_length; p.normalize = h->cfg.normalize; p.padded = h->padded; p.nf = h->nf;
     p.basis = h->basis; p.fbfrag = h->fbfrag; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
     p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out;
+    const char* dbg = getenv("RADAD_DEBUG_LOGMEL");
+    p.debug = dbg ? atoi(dbg) : 0;
     h->prof_logmel.begin(st);
     hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
     h->prof_logmel.end(st);

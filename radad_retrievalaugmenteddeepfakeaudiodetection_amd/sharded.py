@@ -64,14 +64,23 @@ class ShardedSearch:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
-    def gather_queries(self, q_local):
+    def _all_gather(self, t):
+        """[n, ...] per rank -> [world*n, ...] (rank-major).  RCCL gathers device tensors in place; a gloo group
+        (CPU tests, or rehearsing several ranks on one GPU) stages through host memory."""
         import torch
         import torch.distributed as dist
-        if self.world == 1:
-            return q_local
-        out = torch.empty((self.world * q_local.shape[0], q_local.shape[1]), device=q_local.device, dtype=q_local.dtype)
-        dist.all_gather_into_tensor(out, q_local.contiguous(), group=self.group)
+        t = t.contiguous()
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = torch.empty(out.shape, dtype=t.dtype)
+            dist.all_gather_into_tensor(host, t.cpu(), group=self.group)
+            out.copy_(host)
+        else:
+            dist.all_gather_into_tensor(out, t, group=self.group)
         return out
+
+    def gather_queries(self, q_local):
+        return q_local if self.world == 1 else self._all_gather(q_local)
 
     def search(self, q_local, k: int, return_all: bool = False):
         """q_local [Q_r, D] (same Q_r on every rank) -> this rank's rows of the merged result
@@ -84,11 +93,8 @@ class ShardedSearch:
             return d_loc.float(), i_loc
         Q = q_all.shape[0]
         # concatenated output form (accepted by both RCCL and gloo), viewed as [G, Q, k]
-        d_all = torch.empty((self.world * Q, k), device=d_loc.device, dtype=d_loc.dtype)
-        i_all = torch.empty((self.world * Q, k), device=i_loc.device, dtype=i_loc.dtype)
-        dist.all_gather_into_tensor(d_all, d_loc.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(i_all, i_loc.contiguous(), group=self.group)
-        d_all, i_all = d_all.view(self.world, Q, k), i_all.view(self.world, Q, k)
+        d_all = self._all_gather(d_loc).view(self.world, Q, k)
+        i_all = self._all_gather(i_loc).view(self.world, Q, k)
         if return_all:
             return self.merge(self.metric, d_all, i_all, k)
         qr = q_local.shape[0]
