@@ -32,6 +32,11 @@ TOP_K = 10
 AUDIO_SEED, DB_SEED, NOISE_SEED = 1234, 4321, 99
 PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
 PEAK_HBM_GBPS = 8000.0
+# HBM-side bytes of ONE scan launch of the default 1-GPU workload, from the PMC passes of the same command
+# (profiles/r1_b_pmc_summary.txt, tools/profile_r1.sh): FETCH_SIZE 4.184e6 KB x 1024 x 2 (gfx950 reports half of a
+# 16-B/lane stream, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 8.2e3 KB x 1024.  Infinity-Cache hits are counted in
+# FETCH_SIZE, so this is an upper bound on DRAM traffic; it is only meaningful for that exact workload.
+SCAN_TRAFFIC_BYTES_R1B = 4.18399e6 * 1024 * 2 + 8195.59 * 1024
 
 
 def planted_row(j, c, n_total):
@@ -168,7 +173,8 @@ def main():
                    "clips_per_gpu": B, "db_rows": n_total, "dim": DIM, "k": TOP_K, "parallelism": f"shard{world}",
                    "planted_neighbours_found": planted_ok},
         "roofline": {"kernel": "k_knn_f32", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
+                     "traffic": SCAN_TRAFFIC_BYTES_R1B if (world == 1 and B == CLIPS_PER_GPU and n_total == DB_ROWS) else None,
                      "kernel_ms": round(knn_avg, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
                      "hbm_GBps_algorithmic": round(alg_bytes / (knn_avg * 1e-3) / 1e9, 1),
                      "launch": vdb.index.last_launch()},

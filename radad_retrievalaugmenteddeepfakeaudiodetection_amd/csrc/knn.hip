@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <mutex>
 #include <new>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -47,6 +48,7 @@ struct KnnParams {
     int64_t chunk_rows;   // rows per split, multiple of KT_M
     float* part_score;    // [nq, n_splits, k]
     int* part_idx;        // [nq, n_splits, k]
+    int debug;            // timing experiments only (RADAD_DEBUG_KNN): 1 = skip the top-k epilogue
 };
 
 __device__ __forceinline__ bool better(float s, int i, float ws, int wi) {
@@ -60,7 +62,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // chunk / of the query block fall outside num_records and read as zero, and a thread needs only four 32-bit
 // offsets for all of its loads (the K step goes into the scalar offset).
 struct TileCtx {
-    int dim, nk;
+    int dim, nk, debug;
     unsigned voff[4];     // byte offset of (row ld_r + 32 i, col ld_c) inside a tile
     int ld_r, ld_c;
     int wm, wn, l31, lh;
@@ -123,8 +125,174 @@ __device__ __forceinline__ void knn_tile_gemm(const TileCtx& c, __amdgpu_buffer_
     }
 }
 
+// Same tile product, software-pipelined ACROSS tiles: on entry chunk 0 of this tile already sits in LDS buffer
+// (gbuf & 1); during the last K step the first chunk of the NEXT tile is fetched, so no tile starts by waiting
+// for HBM.  On exit buffer (gbuf & 1) holds the next tile's chunk 0 (if has_next) and the other one is free.
+__device__ __forceinline__ void knn_tile_gemm_pipelined(const TileCtx& c, __amdgpu_buffer_rsrc_t cur_desc,
+                                                        __amdgpu_buffer_rsrc_t next_desc, bool has_next,
+                                                        __amdgpu_buffer_rsrc_t rq_desc, float* sA, float* sB, int& gbuf,
+                                                        f32x16 (&acc)[2][2]) {
+    f32x4 ra[4], rb[4];
+    auto gload = [&](__amdgpu_buffer_rsrc_t a_desc, int kc) {
+        const bool kin = kc * KT_K + c.ld_c < c.dim;
+        const int soff = kc * KT_K * (int)sizeof(float);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned vo = kin ? c.voff[i] : 0x7FFF0000u;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_desc, vo, soff, 0));
+            rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rq_desc, vo, soff, 0));
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = c.ld_r + 32 * i;
+            *reinterpret_cast<f32x4*>(sA + (buf * KT_M + r) * KT_LD + c.ld_c) = ra[i];
+            *reinterpret_cast<f32x4*>(sB + (buf * KT_N + r) * KT_LD + c.ld_c) = rb[i];
+        }
+    };
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int kc = 0; kc < c.nk; ++kc) {
+        const int buf = gbuf & 1;
+        const bool more = kc + 1 < c.nk;
+        if (!(c.debug & 2)) {
+            if (more) gload(cur_desc, kc + 1);
+            else if (has_next) gload(next_desc, 0);
+        }
+        const float* a_base = sA + (buf * KT_M + c.wm * 64 + c.l31) * KT_LD + 4 * c.lh;
+        const float* b_base = sB + (buf * KT_N + c.wn * 64 + c.l31) * KT_LD + 4 * c.lh;
+#pragma unroll
+        for (int kk = 0; kk < KT_K / 8; ++kk) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_base + kk * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_base + 32 * KT_LD + kk * 8);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b_base + kk * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(b_base + 32 * KT_LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+            }
+        }
+        if ((more || has_next) && !(c.debug & 4)) swrite(buf ^ 1);
+        if (!(c.debug & 8)) __syncthreads();
+        ++gbuf;
+    }
+}
+
+// (re)load chunk 0 of a tile into buffer `buf`: block prologue, and after the rare overflow path clobbered the tiles
+__device__ __forceinline__ void knn_tile_prime(const TileCtx& c, __amdgpu_buffer_rsrc_t a_desc, __amdgpu_buffer_rsrc_t rq_desc,
+                                               float* sA, float* sB, int buf) {
+    const bool kin = c.ld_c < c.dim;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned vo = kin ? c.voff[i] : 0x7FFF0000u;
+        const int r = c.ld_r + 32 * i;
+        *reinterpret_cast<f32x4*>(sA + (buf * KT_M + r) * KT_LD + c.ld_c) =
+            __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_desc, vo, 0, 0));
+        *reinterpret_cast<f32x4*>(sB + (buf * KT_N + r) * KT_LD + c.ld_c) =
+            __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rq_desc, vo, 0, 0));
+    }
+    __syncthreads();
+}
+
+// ---- LDS-DMA variant of the tile product (register-list kernel) -------------------------------------------------
+// The ablation of the register-staged loop showed the ds_write_b128 pass costing 8 % of the scan (7.84 -> 7.20 ms
+// without it): staging now goes HBM/L2 -> LDS directly with `buffer_load_dwordx4 ... lds`, no VGPR round trip, no
+// ds_write, 32 VGPRs freed.  LDS-DMA writes each wave-instruction's 64 x 16 B linearly, so the tiles are UNPADDED
+// (128-byte rows) and bank conflicts are avoided by an XOR swizzle applied on the SOURCE side and on the reads:
+// 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7).  A 16-lane ds_read_b128 group then covers all 64 banks.
+constexpr int KD_ROW_BYTES = KT_K * 4;            // 128
+constexpr int KD_TILE_BYTES = KT_M * KD_ROW_BYTES;   // 16 KB per operand per buffer
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+struct DmaCtx {
+    int dim, nk, debug;
+    unsigned voff[4];        // byte offset in the tile's global rows of this lane's 16 B, per DMA instruction
+    unsigned dst[4];         // wave-uniform LDS byte offset (within one operand tile) of each DMA instruction
+    unsigned rd_a, rd_b;     // LDS byte offset of this lane's A / B row (mt = 0 / nt = 0)
+    unsigned rd_x;           // (lh ^ swizzle) << 4: XOR-ed with 32*kk gives the chunk offset inside the row
+};
+
+__device__ __forceinline__ DmaCtx make_dma_ctx(int dim, int tid, int debug) {
+    DmaCtx c;
+    c.dim = dim; c.nk = (dim + KT_K - 1) / KT_K; c.debug = debug;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int grp = wave * 4 + i;                 // 8-row group written by this instruction
+        const int r = grp * 8 + (lane >> 3);
+        const int pc = lane & 7;                      // physical chunk this lane fills
+        const int lc = pc ^ ((r >> 1) & 7);           // logical chunk it must fetch
+        c.voff[i] = (unsigned)((r * dim + lc * 4) * (int)sizeof(float));
+        c.dst[i] = (unsigned)(grp * 1024);
+    }
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;
+    c.rd_a = (unsigned)((wm * 64 + l31) * KD_ROW_BYTES);
+    c.rd_b = (unsigned)((wn * 64 + l31) * KD_ROW_BYTES);
+    c.rd_x = (unsigned)((lh ^ ((l31 >> 1) & 7)) << 4);
+    return c;
+}
+
+// issue the 8 DMA loads of one K chunk of (A tile, Q tile) into buffer `buf`
+__device__ __forceinline__ void dma_issue(const DmaCtx& c, __amdgpu_buffer_rsrc_t a_desc, __amdgpu_buffer_rsrc_t q_desc, char* sA,
+                                          char* sB, int buf, int kc) {
+    const int soff = kc * KD_ROW_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_desc, (lds_ptr_t)(sA + buf * KD_TILE_BYTES + c.dst[i]), 16, c.voff[i], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(q_desc, (lds_ptr_t)(sB + buf * KD_TILE_BYTES + c.dst[i]), 16, c.voff[i], soff, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void knn_tile_gemm_dma(const DmaCtx& c, __amdgpu_buffer_rsrc_t cur_desc, __amdgpu_buffer_rsrc_t next_desc,
+                                                  bool has_next, __amdgpu_buffer_rsrc_t q_desc, char* sA, char* sB, int& gbuf,
+                                                  f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int kc = 0; kc < c.nk; ++kc) {
+        const int buf = gbuf & 1;
+        if (!(c.debug & 2)) {
+            if (kc + 1 < c.nk) dma_issue(c, cur_desc, q_desc, sA, sB, buf ^ 1, kc + 1);
+            else if (has_next) dma_issue(c, next_desc, q_desc, sA, sB, buf ^ 1, 0);
+        }
+        const char* a_row = sA + buf * KD_TILE_BYTES + c.rd_a;
+        const char* b_row = sB + buf * KD_TILE_BYTES + c.rd_b;
+#pragma unroll
+        for (int kk = 0; kk < KT_K / 8; ++kk) {
+            const unsigned off = c.rd_x ^ (unsigned)(32 * kk);      // chunk (2kk + lh) ^ swizzle, in bytes
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(a_row + off);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_row + 32 * KD_ROW_BYTES + off);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(b_row + off);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(b_row + 32 * KD_ROW_BYTES + off);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+            }
+        }
+        if (!(c.debug & 8)) __syncthreads();      // waits vmcnt(0): the DMA issued above has landed for everyone
+        ++gbuf;
+    }
+}
+
 __device__ __forceinline__ TileCtx make_tile_ctx(int dim, int tid) {
     TileCtx c;
+    c.debug = 0;
     c.dim = dim;
     c.nk = (dim + KT_K - 1) / KT_K;
     c.ld_r = tid >> 3;
@@ -283,12 +451,11 @@ __device__ __forceinline__ void list_insert(u64 (&l)[KSEL], u64 key) {
 template <int KSEL>
 __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sA = reinterpret_cast<float*>(smem);          // [2][KT_M][KT_LD]
-    float* sB = sA + 2 * KT_M * KT_LD;                   // [2][KT_N][KT_LD]
-    float* s_thr = sB + 2 * KT_N * KT_LD;                // [KT_N] current KSEL-th best score of each query
-    int* s_cnt = reinterpret_cast<int*>(s_thr + KT_N);   // [KT_N] candidates pushed this tile
-    float2* s_cand = reinterpret_cast<float2*>(sA);      // [KT_N][CAND_CAP] (score, row bits); aliases the tiles (epilogue only)
-    float* sS = sA;                                      // [KT_N][KS_LD] score tile of the overflow path (aliases too)
+    char* sA = smem;                                                  // [2][128 rows][128 B], swizzled
+    char* sB = smem + 2 * KD_TILE_BYTES;                              // [2][128 rows][128 B], swizzled
+    float* s_thr = reinterpret_cast<float*>(smem + 4 * KD_TILE_BYTES);   // [KT_N] current KSEL-th best score of each query
+    int* s_cnt = reinterpret_cast<int*>(s_thr + KT_N);                // [KT_N] candidates pushed this tile
+    char* sS = smem;                                                  // [KT_N][512 B] swizzled score tile of the overflow path
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -314,15 +481,29 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
     if (tid < KT_N) { s_thr[tid] = -INFINITY; s_cnt[tid] = 0; }
     __syncthreads();
 
-    const TileCtx tc = make_tile_ctx(p.dim, tid);
+    const DmaCtx dc = make_dma_ctx(p.dim, tid, p.debug);
     const __amdgpu_buffer_rsrc_t q_desc = rows_desc(p.q + (int64_t)q0 * p.dim, min(KT_N, p.nq - q0), p.dim);
     const int ql[2] = {wn * 64 + l31, wn * 64 + 32 + l31};
     const bool qvalid[2] = {q0 + ql[0] < p.nq, q0 + ql[1] < p.nq};
 
+    auto tile_desc = [&](int64_t r0) {
+        return rows_desc(p.db + r0 * p.dim, (int)max((int64_t)0, min((int64_t)KT_M, chunk_end - r0)), p.dim);
+    };
+    int gbuf = 0;
+    if (chunk_begin < chunk_end) {
+        dma_issue(dc, tile_desc(chunk_begin), q_desc, sA, sB, 0, 0);
+        __syncthreads();
+    }
     for (int64_t row0 = chunk_begin; row0 < chunk_end; row0 += KT_M) {
         f32x16 acc[2][2];
-        knn_tile_gemm(tc, rows_desc(p.db + row0 * p.dim, (int)min((int64_t)KT_M, chunk_end - row0), p.dim), q_desc, sA, sB, acc);
-
+        const bool has_next = row0 + KT_M < chunk_end;
+        knn_tile_gemm_dma(dc, tile_desc(row0), tile_desc(row0 + KT_M), has_next, q_desc, sA, sB, gbuf, acc);
+        // buffer (gbuf & 1) now holds the next tile's first chunk; the candidate slots alias the OTHER (consumed) A buffer
+        float2* s_cand = reinterpret_cast<float2*>(sA + ((gbuf & 1) ^ 1) * KD_TILE_BYTES);   // [KT_N][CAND_CAP]
+        if (p.debug & 1) {      // timing experiment: keep the accumulators alive, skip the epilogue
+            if (acc[0][0][0] + acc[0][1][5] + acc[1][0][9] + acc[1][1][15] == 12345.678f) s_thr[tid & 127] = 1.f;
+            continue;
+        }
         // ---- fused top-k epilogue -------------------------------------------------------------------------
         const int rowlimit = (int)min((int64_t)KT_M, chunk_end - row0);
         if (p.l2) {
@@ -374,23 +555,24 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
             s_cnt[tid] = 0;
         }
         if (__syncthreads_or(over ? 1 : 0)) {
-            // overflow path (exact, slower): park the score tile query-major and let the owners re-read their rows
+            // overflow path (exact, slower): park the score tile query-major (512-byte rows, 16-byte chunk c of query
+            // q at chunk c ^ (q & 15): conflict-free b128 writes and reads) and let the owners re-read their rows.
+            // It overwrites every tile buffer, so the prefetched chunk is fetched again afterwards.
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int rl = wm * 64 + mt * 32 + 8 * g + 4 * lh;
+                    const int ch = (wm * 64 + mt * 32 + 8 * g + 4 * lh) >> 2;   // rows 4ch..4ch+3 = registers 4g..4g+3
                     f32x4 v0, v1;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { v0[i] = acc[mt][0][4 * g + i]; v1[i] = acc[mt][1][4 * g + i]; }
-                    *reinterpret_cast<f32x4*>(sS + (wn * 64 + l31) * KS_LD + rl) = v0;
-                    *reinterpret_cast<f32x4*>(sS + (wn * 64 + 32 + l31) * KS_LD + rl) = v1;
+                    *reinterpret_cast<f32x4*>(sS + ql[0] * 512 + ((ch ^ (ql[0] & 15)) << 4)) = v0;
+                    *reinterpret_cast<f32x4*>(sS + ql[1] * 512 + ((ch ^ (ql[1] & 15)) << 4)) = v1;
                 }
             __syncthreads();
             if (over) {
-                const float* srow = sS + tid * KS_LD;
                 for (int c = 0; c < rowlimit; c += 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(srow + c);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(sS + tid * 512 + (((c >> 2) ^ (tid & 15)) << 4));
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         if (c + i < rowlimit) list_insert<KSEL>(lst, pack_key(v[i], (int)(row0 + c + i)));
@@ -398,6 +580,10 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
                 s_thr[tid] = key_score(lst[KSEL - 1]);
             }
             __syncthreads();
+            if (has_next) {
+                dma_issue(dc, tile_desc(row0 + KT_M), q_desc, sA, sB, gbuf & 1, 0);
+                __syncthreads();
+            }
         }
     }
     // the lists leave the registers once, at the end of the chunk
@@ -410,7 +596,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
     }
 }
 
-constexpr size_t knn_reg_lds_bytes() { return sizeof(float) * (2 * KT_M * KT_LD + 2 * KT_N * KT_LD + KT_N) + sizeof(int) * KT_N; }
+constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float) * KT_N + sizeof(int) * KT_N; }
 
 // ---- merge of sorted partial lists -----------------------------------------------------------------------
 // element (part, q, j) of a list sits at [part*sp + q*sq + j]; lists are sorted best-first and padded with
@@ -853,16 +1039,17 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     p.db = h->rows; p.ynorm = h->ynorm; p.q = q_use; p.n = h->ntotal; p.nq = (int)nq; p.dim = h->dim; p.k = ksel;
     p.l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0;
     p.n_qtiles = n_qtiles; p.n_splits = n_splits; p.chunk_rows = chunk_rows; p.part_score = ps; p.part_idx = pi;
+    { const char* dbg = getenv("RADAD_DEBUG_KNN"); p.debug = dbg ? atoi(dbg) : 0; }
     // > 64 KB of dynamic LDS: raise the limit (per device, so on every call).  Lists live in registers when
     // k + margin fits 16 or 32 entries (k <= 26), otherwise in the partial-result arrays (generic kernel).
     const dim3 grid((unsigned)(n_qtiles * n_splits));
-    if (ksel <= 16) {
+    if (ksel <= 16 && h->dim % KT_K == 0) {
         RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32_reg<16>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_reg_lds_bytes()));
         h->prof.begin(st);
         hipLaunchKernelGGL(k_knn_f32_reg<16>, grid, dim3(KNN_THREADS), knn_reg_lds_bytes(), st, p);
         h->prof.end(st);
-    } else if (ksel <= 32) {
+    } else if (ksel <= 32 && h->dim % KT_K == 0) {
         RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32_reg<32>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_reg_lds_bytes()));
         h->prof.begin(st);
