@@ -596,6 +596,142 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
     }
 }
 
+// ---- small-batch scan (nq <= 16: the online `predict` case, pipeline.py:1038-1054) ------------------------------
+// With a handful of queries the scan is HBM-bound (2 flop per stored byte per query), so the 128-query tile above
+// would burn 8x-128x the needed MFMA time.  Here every WAVE streams its own slice of the store, 16 rows per step,
+// whole 2 KB rows in one burst of 16-byte loads straight from HBM into registers (no LDS for the store: it is read exactly once), against the <=16 queries parked in LDS.
+// v_mfma_f32_16x16x4_f32 with the store rows as A and the queries as B leaves a lane with ONE query column
+// (lane & 15) and 4 rows per group, so the filter threshold is a register.  Each wave keeps private top-k lists
+// (lanes 0-15 own one query each, lists in registers); survivors travel through a per-wave LDS slot buffer that can
+// never overflow (16 slots per query = everything one step can produce).  No workgroup barrier inside the scan.
+constexpr int SQ_THREADS = 256;
+constexpr int SQ_NQ = 16;
+constexpr int SQ_SLOTS = 16;
+constexpr int SQ_MAX_DIM = 2048;
+
+struct SmallQParams {
+    const float* db; const float* ynorm; const float* q;
+    int64_t n;
+    int nq, dim, k, l2;
+    int rows_per_wave;          // multiple of 16
+    int n_parts;                // workgroups = lists per query
+    float* part_score; int* part_idx;   // [nq, n_parts, k]
+};
+
+template <int KSEL>
+__global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_f32_smallq(SmallQParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int qld = p.dim + 4;                                    // padded query row: conflict-free b128 reads
+    float* sQ = reinterpret_cast<float*>(smem);                   // [16][dim + 4]
+    float2* sCand = reinterpret_cast<float2*>(sQ + SQ_NQ * qld);  // [4 waves][16 q][SQ_SLOTS]
+    int* sCnt = reinterpret_cast<int*>(sCand + 4 * SQ_NQ * 24);         // [4 waves][16]; the slot area is sized for the final
+                                                                        // hand-over of 3 x 16 x 32 keys (12 KB) as well
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    for (int i = tid; i < SQ_NQ * (p.dim >> 2); i += SQ_THREADS) {
+        const int qq = i / (p.dim >> 2), c4 = i % (p.dim >> 2);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (qq < p.nq) v = *reinterpret_cast<const f32x4*>(p.q + (int64_t)qq * p.dim + c4 * 4);
+        *reinterpret_cast<f32x4*>(sQ + qq * qld + c4 * 4) = v;
+    }
+    if (tid < 4 * SQ_NQ) sCnt[tid] = 0;
+    __syncthreads();
+
+    const int part = blockIdx.x * 4 + wave;      // this wave's slice of the store
+    const int64_t w_begin = (int64_t)part * p.rows_per_wave;
+    const int64_t w_end = min(w_begin + p.rows_per_wave, p.n);
+    float2* myCand = sCand + wave * SQ_NQ * SQ_SLOTS;
+    int* myCnt = sCnt + wave * SQ_NQ;
+
+    const u64 SENT = pack_key(-INFINITY, IDX_SENTINEL);
+    u64 lst[KSEL];                       // meaningful in lanes 0..15 (lane = query)
+#pragma unroll
+    for (int j = 0; j < KSEL; ++j) lst[j] = SENT;
+    float thr = -INFINITY;               // threshold of query (lane & 15), refreshed from the owner lane
+    // K mapping inside a 32-float block: load h (0/1), element j of lane group g is k = 16h + 4g + j, so one load
+    // instruction reads 64 CONTIGUOUS bytes of each of its 16 rows and the pair covers the whole 128-byte line.
+    const float* qrow = sQ + r16 * qld + 4 * g;
+    const int nkb = p.dim >> 5;
+
+    for (int64_t row0 = w_begin; row0 < w_end; row0 += 16) {
+        // 16 rows per step; a lane issues ALL its loads of a 512-float panel (32 x 16 B = the whole 2 KB row at
+        // dim 512) before the first MFMA, so each row is fetched in one burst and 32 loads per lane are in flight.
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // even / odd K blocks: two MFMA chains
+        const int64_t ra = min(row0 + r16, p.n - 1);                             // clamp: masked below
+        const float* pa = p.db + ra * p.dim + 4 * g;
+        constexpr int PKB = KSEL <= 16 ? 16 : 8;      // K blocks per panel (the 32-entry lists leave fewer registers)
+        for (int kp = 0; kp < nkb; kp += PKB) {
+            const int nb = min(PKB, nkb - kp);
+            f32x4 v[2 * PKB];
+#pragma unroll
+            for (int kb = 0; kb < PKB; ++kb)
+                if (kb < nb) {
+                    v[2 * kb] = *reinterpret_cast<const f32x4*>(pa + (kp + kb) * 32);
+                    v[2 * kb + 1] = *reinterpret_cast<const f32x4*>(pa + (kp + kb) * 32 + 16);
+                }
+#pragma unroll
+            for (int kb = 0; kb < PKB; ++kb)
+                if (kb < nb) {
+                    const f32x4 q0 = *reinterpret_cast<const f32x4*>(qrow + (kp + kb) * 32);
+                    const f32x4 q1 = *reinterpret_cast<const f32x4*>(qrow + (kp + kb) * 32 + 16);
+                    if (kb & 1) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * kb][j], q0[j], acc1, 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * kb + 1][j], q1[j], acc1, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * kb][j], q0[j], acc0, 0, 0, 0);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v[2 * kb + 1][j], q1[j], acc0, 0, 0, 0);
+                    }
+                }
+        }
+        // acc0[e] + acc1[e]: row row0 + 4g + e, query r16
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t row = row0 + 4 * g + e;
+            float sc = acc0[e] + acc1[e];
+            if (p.l2) sc = 2.f * sc - p.ynorm[min(row, p.n - 1)];
+            if (row < w_end && r16 < p.nq && sc >= thr) {
+                const int sl = atomicAdd(&myCnt[r16], 1);          // < SQ_SLOTS by construction (4 x 4 lanes)
+                myCand[r16 * SQ_SLOTS + sl] = make_float2(sc, __int_as_float((int)row));
+                any = true;
+            }
+        }
+        if (__any(any)) {                                              // wave-uniform; LDS ops of one wave are ordered
+            if (lane < SQ_NQ) {
+                const int c = myCnt[lane];
+                for (int i = 0; i < c; ++i) {
+                    const float2 cv = myCand[lane * SQ_SLOTS + i];
+                    list_insert<KSEL>(lst, pack_key(cv.x, __float_as_int(cv.y)));
+                }
+                myCnt[lane] = 0;
+            }
+            thr = __shfl(key_score(lst[KSEL - 1]), r16, 64);
+        }
+    }
+    // one list per WORKGROUP leaves the kernel: waves 1-3 hand their lists to wave 0 through the slot buffer
+    __syncthreads();
+    u64* sKeys = reinterpret_cast<u64*>(sCand);                     // [3][16][KSEL] (<= the slot buffer's 16 KB)
+    if (wave > 0 && lane < SQ_NQ) {
+#pragma unroll
+        for (int j = 0; j < KSEL; ++j) sKeys[((wave - 1) * SQ_NQ + lane) * KSEL + j] = lst[j];
+    }
+    __syncthreads();
+    if (wave == 0 && lane < p.nq) {
+        for (int w = 0; w < 3; ++w)
+            for (int j = 0; j < KSEL; ++j) list_insert<KSEL>(lst, sKeys[(w * SQ_NQ + lane) * KSEL + j]);
+        float* ls = p.part_score + ((int64_t)lane * p.n_parts + blockIdx.x) * p.k;
+        int* li = p.part_idx + ((int64_t)lane * p.n_parts + blockIdx.x) * p.k;
+#pragma unroll
+        for (int j = 0; j < KSEL; ++j)
+            if (j < p.k) { ls[j] = key_score(lst[j]); li[j] = key_id(lst[j]); }
+    }
+}
+
 constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float) * KT_N + sizeof(int) * KT_N; }
 
 // ---- merge of sorted partial lists -----------------------------------------------------------------------
@@ -1003,6 +1139,17 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     int n_qtiles, n_splits;
     int64_t chunk_rows;
     knn_geometry(std::max<int64_t>(h->ntotal, 1), nq, &n_qtiles, &n_splits, &chunk_rows);
+    // small batches (the online predict case) take the HBM-bound streaming kernel: one list per WAVE
+    const bool smallq = nq <= SQ_NQ && h->dim % 32 == 0 && h->dim <= SQ_MAX_DIM && k + KNN_MARGIN <= 32 && h->ntotal > 0;
+    int sq_rows_per_wave = 0;
+    if (smallq) {
+        const int64_t waves_wanted = 256 * 8;                                     // 8 waves (2 workgroups) per CU
+        int64_t rpw = ceil_div64(ceil_div64(h->ntotal, waves_wanted), 16) * 16;
+        rpw = std::max<int64_t>(rpw, 128);
+        sq_rows_per_wave = (int)rpw;
+        n_splits = (int)ceil_div64(ceil_div64(h->ntotal, rpw), 4);                // workgroups of 4 waves = lists per query
+        n_qtiles = 1;
+    }
     h->last_qtiles = n_qtiles;
     h->last_splits = n_splits;
 
@@ -1043,7 +1190,27 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     // > 64 KB of dynamic LDS: raise the limit (per device, so on every call).  Lists live in registers when
     // k + margin fits 16 or 32 entries (k <= 26), otherwise in the partial-result arrays (generic kernel).
     const dim3 grid((unsigned)(n_qtiles * n_splits));
-    if (ksel <= 16 && h->dim % KT_K == 0) {
+    if (smallq) {
+        SmallQParams sp;
+        sp.db = h->rows; sp.ynorm = h->ynorm; sp.q = q_use; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel;
+        sp.l2 = p.l2; sp.rows_per_wave = sq_rows_per_wave; sp.n_parts = n_splits; sp.part_score = ps; sp.part_idx = pi;
+        const size_t slot_bytes = std::max<size_t>(sizeof(float2) * 4 * SQ_NQ * SQ_SLOTS, sizeof(u64) * 3 * SQ_NQ * 32);
+        const size_t lds = sizeof(float) * SQ_NQ * (h->dim + 4) + slot_bytes + sizeof(int) * 4 * SQ_NQ;
+        const dim3 sgrid((unsigned)n_splits);
+        if (ksel <= 16) {
+            RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32_smallq<16>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            h->prof.begin(st);
+            hipLaunchKernelGGL(k_knn_f32_smallq<16>, sgrid, dim3(SQ_THREADS), lds, st, sp);
+            h->prof.end(st);
+        } else {
+            RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32_smallq<32>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            h->prof.begin(st);
+            hipLaunchKernelGGL(k_knn_f32_smallq<32>, sgrid, dim3(SQ_THREADS), lds, st, sp);
+            h->prof.end(st);
+        }
+    } else if (ksel <= 16 && h->dim % KT_K == 0) {
         RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32_reg<16>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_reg_lds_bytes()));
         h->prof.begin(st);
