@@ -46,7 +46,7 @@ constexpr int NMT = 3;                  // mel tiles of 32 (96 >= 80)
 constexpr int CHUNK_FLOATS = KCH * 2 * 64 * 4;   // 2560 floats = 10 KB
 constexpr int MAX_SEG_LEN = 32000;
 constexpr int SIG_FLOATS = 32800;       // (160*201+400) * 161/160 rounded up
-constexpr int MAX_BINS_TOTAL = 32;      // sum(levels)
+constexpr int MAX_BINS_TOTAL = 16;      // sum(levels)
 
 __device__ __forceinline__ int sig_pos(int c) { return c + c / FFT_HOP; }   // +1 float per 160: bank-conflict-free frame stride
 
@@ -264,9 +264,8 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
 }
 
 // ---- projection + pooling -----------------------------------------------------------------------------
-constexpr int PP_WAVES = 8;            // 8 waves x 32 features = 256 features per workgroup
-constexpr int PP_THREADS = PP_WAVES * 64;
-constexpr int PP_FEATS = PP_WAVES * 32;
+// WAVES x 32 features per workgroup: 16 waves (all 512 features of the benchmark: each segment's log-mel is staged once
+// per clip) when F > 256, 8 waves otherwise
 constexpr int PP_FB = 224;           // frames staged per block pass (7 tiles)
 constexpr int PP_LD = N_MELS + 4;    // padded log-mel row in LDS (84 floats: conflict-free b128 frame reads)
 
@@ -286,8 +285,10 @@ struct ProjPoolParams {
     float* frames_out;          // optional [S][T][F]: per-frame features (extract_features protocol); no pooling
 };
 
-template <bool FRAMES_OUT>
-__global__ __launch_bounds__(PP_THREADS, 2) void k_proj_pool(ProjPoolParams p) {
+template <bool FRAMES_OUT, int PP_WAVES>
+__global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjPoolParams p) {
+    constexpr int PP_THREADS = PP_WAVES * 64;
+    constexpr int PP_FEATS = PP_WAVES * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* slm = reinterpret_cast<float*>(smem);             // [PP_FB][PP_LD]
     float* spool = slm + PP_FB * PP_LD;                      // [nbins][PP_FEATS]  current segment
@@ -375,13 +376,22 @@ __global__ __launch_bounds__(PP_THREADS, 2) void k_proj_pool(ProjPoolParams p) {
                             const int hi = (int)(((int64_t)(i + 1) * p.T + lv - 1) / lv);
                             if (hi <= tfirst || lo >= tlast) continue;        // wave-uniform
                             float v = p.pool_mode == RADAD_POOL_MAX ? -INFINITY : 0.f;
+                            if (lo <= tfirst && tfirst + 32 <= hi) {       // whole tile inside the bin (wave-uniform)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int tt = tfirst + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                                const bool in = tt >= lo && tt < hi;       // hi <= T
-                                const float x = acc[r] + bias;
-                                if (p.pool_mode == RADAD_POOL_MAX) v = in ? fmaxf(v, x) : v;
-                                else v += in ? x : 0.f;
+                                for (int r = 0; r < 16; ++r) {
+                                    const float x = acc[r] + bias;
+                                    if (p.pool_mode == RADAD_POOL_MAX) v = fmaxf(v, x);
+                                    else v += x;
+                                }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int tt = tfirst + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                                    const bool in = tt >= lo && tt < hi;       // hi <= T
+                                    const float x = acc[r] + bias;
+                                    if (p.pool_mode == RADAD_POOL_MAX) v = in ? fmaxf(v, x) : v;
+                                    else v += in ? x : 0.f;
+                                }
                             }
                             const float o = __shfl_xor(v, 32, 64);
                             if (lh == 0) {
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(256) void k_group_mean(const float* __restrict__ in
 }
 
 constexpr size_t logmel_lds_bytes() { return sizeof(float) * (SIG_FLOATS + 2 * CHUNK_FLOATS + 16); }
-constexpr size_t projpool_lds_bytes() { return sizeof(float) * (PP_FB * PP_LD + 2 * MAX_BINS_TOTAL * PP_FEATS); }
+constexpr size_t projpool_lds_bytes(int waves) { return sizeof(float) * (PP_FB * PP_LD + 2 * MAX_BINS_TOTAL * waves * 32); }
 
 // growable device buffer
 struct DevBuf {
@@ -702,10 +712,12 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
     if (!rc) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)logmel_lds_bytes()) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)projpool_lds_bytes()) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)projpool_lds_bytes()) != hipSuccess) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)projpool_lds_bytes(8)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)projpool_lds_bytes(16)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<true, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)projpool_lds_bytes(8)) != hipSuccess) {
             radad_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
             rc = RADAD_EHIP;
         }
@@ -752,8 +764,11 @@ int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* c
     fill_projpool(h, p);
     p.out = out_dev;
     h->prof_pool.begin(st);
-    hipLaunchKernelGGL(k_proj_pool<false>, dim3((unsigned)n_clips, (unsigned)((h->cfg.feat_dim + PP_FEATS - 1) / PP_FEATS)), dim3(PP_THREADS),
-                       projpool_lds_bytes(), st, p);
+    if (h->cfg.feat_dim > 256)
+        hipLaunchKernelGGL((k_proj_pool<false, 16>), dim3((unsigned)n_clips, (unsigned)((h->cfg.feat_dim + 511) / 512)), dim3(1024),
+                           projpool_lds_bytes(16), st, p);
+    else
+        hipLaunchKernelGGL((k_proj_pool<false, 8>), dim3((unsigned)n_clips, 1), dim3(512), projpool_lds_bytes(8), st, p);
     h->prof_pool.end(st);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
@@ -825,8 +840,8 @@ int radad_embed_frame_features(radad_embed_t h, const float* wave_dev, const int
     ProjPoolParams p;
     fill_projpool(h, p);
     p.frames_out = out_dev;
-    hipLaunchKernelGGL(k_proj_pool<true>, dim3((unsigned)n_seg, (unsigned)((h->cfg.feat_dim + PP_FEATS - 1) / PP_FEATS)), dim3(PP_THREADS),
-                       projpool_lds_bytes(), st, p);
+    hipLaunchKernelGGL((k_proj_pool<true, 8>), dim3((unsigned)n_seg, (unsigned)((h->cfg.feat_dim + 255) / 256)), dim3(512),
+                       projpool_lds_bytes(8), st, p);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
 }
