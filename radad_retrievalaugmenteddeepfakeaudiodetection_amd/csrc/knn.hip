@@ -253,9 +253,10 @@ __device__ __forceinline__ void dma_issue(const DmaCtx& c, __amdgpu_buffer_rsrc_
     }
 }
 
+template <typename Hook>
 __device__ __forceinline__ void knn_tile_gemm_dma(const DmaCtx& c, __amdgpu_buffer_rsrc_t cur_desc, __amdgpu_buffer_rsrc_t next_desc,
                                                   bool has_next, __amdgpu_buffer_rsrc_t q_desc, char* sA, char* sB, int& gbuf,
-                                                  f32x16 (&acc)[2][2]) {
+                                                  f32x16 (&acc)[2][2], Hook&& after_first_barrier) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -287,6 +288,7 @@ __device__ __forceinline__ void knn_tile_gemm_dma(const DmaCtx& c, __amdgpu_buff
         }
         if (!(c.debug & 8)) __syncthreads();      // waits vmcnt(0): the DMA issued above has landed for everyone
         ++gbuf;
+        if (kc == 0) after_first_barrier();       // work deferred from the previous tile's epilogue (no barriers inside)
     }
 }
 
@@ -453,8 +455,11 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                                                  // [2][128 rows][128 B], swizzled
     char* sB = smem + 2 * KD_TILE_BYTES;                              // [2][128 rows][128 B], swizzled
-    float* s_thr = reinterpret_cast<float*>(smem + 4 * KD_TILE_BYTES);   // [KT_N] current KSEL-th best score of each query
+    float2* s_cand = reinterpret_cast<float2*>(smem + 4 * KD_TILE_BYTES);   // [KT_N][CAND_CAP] (score, row bits), NOT aliased:
+                                                                      // it outlives the tile (drained during the next K loop)
+    float* s_thr = reinterpret_cast<float*>(s_cand + KT_N * CAND_CAP);   // [KT_N] current KSEL-th best score of each query
     int* s_cnt = reinterpret_cast<int*>(s_thr + KT_N);                // [KT_N] candidates pushed this tile
+    int* s_flag = s_cnt + KT_N;                                       // [1] some query overflowed its slots this tile
     char* sS = smem;                                                  // [KT_N][512 B] swizzled score tile of the overflow path
 
     const int tid = threadIdx.x;
@@ -479,6 +484,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
 #pragma unroll
     for (int j = 0; j < KSEL; ++j) lst[j] = SENT;
     if (tid < KT_N) { s_thr[tid] = -INFINITY; s_cnt[tid] = 0; }
+    if (tid == 0) *s_flag = 0;
     __syncthreads();
 
     const DmaCtx dc = make_dma_ctx(p.dim, tid, p.debug);
@@ -494,12 +500,27 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
         dma_issue(dc, tile_desc(chunk_begin), q_desc, sA, sB, 0, 0);
         __syncthreads();
     }
+    // owners fold their slot buffer into the register list; no barrier inside, so it can run in the shadow of the
+    // next tile's MFMA work (the pushes it reads were published by the epilogue's barrier)
+    auto drain = [&]() {
+        if (owner) {
+            const int c = min(s_cnt[tid], CAND_CAP);
+            if (c > 0) {
+                for (int i = 0; i < c; ++i) {
+                    const float2 cv = s_cand[tid * CAND_CAP + i];
+                    list_insert<KSEL>(lst, pack_key(cv.x, __float_as_int(cv.y)));
+                }
+                s_thr[tid] = key_score(lst[KSEL - 1]);
+            }
+        }
+        if (tid < KT_N) s_cnt[tid] = 0;
+    };
+    bool pending = false;
     for (int64_t row0 = chunk_begin; row0 < chunk_end; row0 += KT_M) {
         f32x16 acc[2][2];
         const bool has_next = row0 + KT_M < chunk_end;
-        knn_tile_gemm_dma(dc, tile_desc(row0), tile_desc(row0 + KT_M), has_next, q_desc, sA, sB, gbuf, acc);
-        // buffer (gbuf & 1) now holds the next tile's first chunk; the candidate slots alias the OTHER (consumed) A buffer
-        float2* s_cand = reinterpret_cast<float2*>(sA + ((gbuf & 1) ^ 1) * KD_TILE_BYTES);   // [KT_N][CAND_CAP]
+        knn_tile_gemm_dma(dc, tile_desc(row0), tile_desc(row0 + KT_M), has_next, q_desc, sA, sB, gbuf, acc,
+                          [&]() { if (pending) { drain(); pending = false; } });
         if (p.debug & 1) {      // timing experiment: keep the accumulators alive, skip the epilogue
             if (acc[0][0][0] + acc[0][1][5] + acc[1][0][9] + acc[1][1][15] == 12345.678f) s_thr[tid & 127] = 1.f;
             continue;
@@ -534,56 +555,53 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
                             const int sl = atomicAdd(&s_cnt[ql[nt]], 1);
                             if (sl < CAND_CAP)
                                 s_cand[ql[nt] * CAND_CAP + sl] = make_float2(acc[mt][nt][r], __int_as_float((int)(row0 + rl)));
+                            else
+                                *s_flag = 1;
                         }
                     }
                 }
             }
         }
-        __syncthreads();
-        // phase 2: owners drain their buffers into the register lists
-        bool over = false;
-        if (tid < KT_N) {
-            const int c = s_cnt[tid];
-            over = owner && c > CAND_CAP;
-            if (owner && !over && c > 0) {
-                for (int i = 0; i < c; ++i) {
-                    const float2 cv = s_cand[tid * CAND_CAP + i];
-                    list_insert<KSEL>(lst, pack_key(cv.x, __float_as_int(cv.y)));
-                }
-                s_thr[tid] = key_score(lst[KSEL - 1]);
+        __syncthreads();                 // pushes, counters and the overflow flag are visible to everyone
+        if (*s_flag == 0) {
+            // common case: nothing overflowed.  The drain is deferred into the next tile's K loop (or done right here
+            // for the last tile); no second barrier, the next K loop's own barriers order everything.
+            if (has_next) pending = true;
+            else drain();
+            continue;
+        }
+        // overflow path (exact, slower; always the first tile of a chunk): owners whose slots sufficed drain them, the
+        // others re-read their whole row from the score tile, parked query-major over the tile buffers (512-byte rows,
+        // 16-byte chunk c of query q at chunk c ^ (q & 15): conflict-free b128 writes and reads).
+        const bool over = owner && s_cnt[tid] > CAND_CAP;
+        if (!over) drain();
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = (wm * 64 + mt * 32 + 8 * g + 4 * lh) >> 2;   // rows 4ch..4ch+3 = registers 4g..4g+3
+                f32x4 v0, v1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v0[i] = acc[mt][0][4 * g + i]; v1[i] = acc[mt][1][4 * g + i]; }
+                *reinterpret_cast<f32x4*>(sS + ql[0] * 512 + ((ch ^ (ql[0] & 15)) << 4)) = v0;
+                *reinterpret_cast<f32x4*>(sS + ql[1] * 512 + ((ch ^ (ql[1] & 15)) << 4)) = v1;
             }
+        __syncthreads();
+        if (tid == 0) *s_flag = 0;
+        if (over) {
+            for (int c = 0; c < rowlimit; c += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sS + tid * 512 + (((c >> 2) ^ (tid & 15)) << 4));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (c + i < rowlimit) list_insert<KSEL>(lst, pack_key(v[i], (int)(row0 + c + i)));
+            }
+            s_thr[tid] = key_score(lst[KSEL - 1]);
             s_cnt[tid] = 0;
         }
-        if (__syncthreads_or(over ? 1 : 0)) {
-            // overflow path (exact, slower): park the score tile query-major (512-byte rows, 16-byte chunk c of query
-            // q at chunk c ^ (q & 15): conflict-free b128 writes and reads) and let the owners re-read their rows.
-            // It overwrites every tile buffer, so the prefetched chunk is fetched again afterwards.
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch = (wm * 64 + mt * 32 + 8 * g + 4 * lh) >> 2;   // rows 4ch..4ch+3 = registers 4g..4g+3
-                    f32x4 v0, v1;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { v0[i] = acc[mt][0][4 * g + i]; v1[i] = acc[mt][1][4 * g + i]; }
-                    *reinterpret_cast<f32x4*>(sS + ql[0] * 512 + ((ch ^ (ql[0] & 15)) << 4)) = v0;
-                    *reinterpret_cast<f32x4*>(sS + ql[1] * 512 + ((ch ^ (ql[1] & 15)) << 4)) = v1;
-                }
+        __syncthreads();
+        if (has_next) {                  // the score tile overwrote the prefetched chunk: fetch it again
+            dma_issue(dc, tile_desc(row0 + KT_M), q_desc, sA, sB, gbuf & 1, 0);
             __syncthreads();
-            if (over) {
-                for (int c = 0; c < rowlimit; c += 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(sS + tid * 512 + (((c >> 2) ^ (tid & 15)) << 4));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (c + i < rowlimit) list_insert<KSEL>(lst, pack_key(v[i], (int)(row0 + c + i)));
-                }
-                s_thr[tid] = key_score(lst[KSEL - 1]);
-            }
-            __syncthreads();
-            if (has_next) {
-                dma_issue(dc, tile_desc(row0 + KT_M), q_desc, sA, sB, gbuf & 1, 0);
-                __syncthreads();
-            }
         }
     }
     // the lists leave the registers once, at the end of the chunk
@@ -732,7 +750,7 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_f32_smallq(SmallQParams p
     }
 }
 
-constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float) * KT_N + sizeof(int) * KT_N; }
+constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float2) * KT_N * CAND_CAP + sizeof(float) * KT_N + sizeof(int) * KT_N + 16; }
 
 // ---- merge of sorted partial lists -----------------------------------------------------------------------
 // element (part, q, j) of a list sits at [part*sp + q*sq + j]; lists are sorted best-first and padded with

@@ -51,6 +51,33 @@ def test_knn_matches_oracle(gpu, metric, n, nq, dim, k):
     _assert_separated(od, D)
 
 
+@pytest.mark.parametrize("metric", ["L2", "COSINE"])
+@pytest.mark.parametrize("n,nq,dim,k", [(3000, 40, 5376, 15),      # the reference's own D (7 x 768) and k_search = K + 10
+                                        (4000, 130, 100, 12),      # dim not a multiple of 32: generic kernel, K tail
+                                        (6000, 70, 64, 40),        # k + margin > 32: lists in the partial arrays
+                                        (2500, 9, 96, 30),         # small batch with k too large for the streaming kernel
+                                        (5000, 16, 2048, 10),      # streaming kernel at its largest dim
+                                        (5000, 3, 4096, 10)])      # small batch, dim beyond the streaming kernel
+def test_knn_kernel_variants(gpu, metric, n, nq, dim, k):
+    """every dispatch branch of radad_knn_search: tile kernel with register lists (16/32), generic tile kernel,
+    streaming small-batch kernel"""
+    db = synth.rows(0, n, dim, 1001)
+    q = synth.rows(0, nq, dim, 1002)
+    for j in range(nq):
+        db[(j * 13 + 5) % n] = q[j] + np.float32(0.1) * synth.rows(j, 1, dim, 1003)[0]
+    idx = _mk(gpu, metric, dim)
+    idx.add(db)
+    D, I = idx.search(q, k)
+    od, oi = O.knn(db, q, k, metric)
+    _check(D, I, od, oi, metric, unit=(metric == "COSINE"))
+
+
+def test_knn_empty_store(gpu):
+    idx = _mk(gpu, "L2", 32)
+    D, I = idx.search(synth.rows(0, 3, 32, 1), 4)
+    assert np.all(I == -1) and np.all(np.isinf(D)) and idx.ntotal == 0
+
+
 def test_knn_device_tensors_and_reconstruct(gpu):
     import torch
     n, dim, k = 5000, 128, 8
