@@ -120,6 +120,14 @@ int radad_topk_merge_f64(int metric, const double* in_key_dev, const int64_t* in
                          int k, float* out_dist_dev, int64_t* out_idx_dev, double* out_key_dev, int device,
                          void* stream);
 
+/* Device-side form of the exclusion loop of retrieve_similar_vectors (pipeline.py:491-515): for every query row keep,
+ * in order, the first k_keep of its k_in search hits whose row tag is NOT in the exclusion set; pad with id -1 and
+ * distance NaN.  row_tags_dev [ntotal] int64 (e.g. a hash of os.path.basename(path), one per stored row, indexed by
+ * id - id_base); excl_sorted_dev [n_excl] int64 ascending (may be NULL when n_excl == 0); hits with id < 0 are skipped. */
+int radad_filter_topk(const float* in_dist_dev, const int64_t* in_idx_dev, int64_t nq, int k_in, int k_keep,
+                      const int64_t* row_tags_dev, int64_t ntotal, int64_t id_base, const int64_t* excl_sorted_dev,
+                      int64_t n_excl, float* out_dist_dev, int64_t* out_idx_dev, int device, void* stream);
+
 /* row L2 normalisation x / (|x| + 1e-12)  (vector_database.py:100-105); in-place allowed */
 int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int device, void* stream);
 

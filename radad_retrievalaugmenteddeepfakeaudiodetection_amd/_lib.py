@@ -62,6 +62,8 @@ SIGNATURES = {
                                    C.c_void_p, C.c_int, C.c_void_p]),
     "radad_topk_merge_f64": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "radad_filter_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
+                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "radad_rownorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "radad_embed_create": (C.c_int, [C.POINTER(EmbedCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(C.c_void_p)]),

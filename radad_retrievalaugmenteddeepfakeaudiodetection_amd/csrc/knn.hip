@@ -955,6 +955,39 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ d
     for (int i = lane; i < (dim >> 2); i += 64) dst[i] = ok ? src[i] : z;
 }
 
+// exclusion + compaction of search hits (retrieve_similar_vectors, pipeline.py:491-515): one thread per query row
+__global__ __launch_bounds__(256) void k_filter_topk(const float* __restrict__ in_dist, const int64_t* __restrict__ in_idx,
+                                                     int64_t nq, int k_in, int k_keep, const int64_t* __restrict__ tags,
+                                                     int64_t ntotal, int64_t id_base, const int64_t* __restrict__ excl,
+                                                     int64_t n_excl, float* __restrict__ out_dist, int64_t* __restrict__ out_idx) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int kept = 0;
+    for (int j = 0; j < k_in && kept < k_keep; ++j) {
+        const int64_t id = in_idx[q * k_in + j];
+        const int64_t r = id - id_base;
+        if (id < 0 || r < 0 || r >= ntotal) continue;
+        bool drop = false;
+        if (n_excl > 0) {
+            const int64_t t = tags[r];
+            int64_t lo = 0, hi = n_excl;                    // binary search in the sorted exclusion set
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (excl[mid] < t) lo = mid + 1; else hi = mid;
+            }
+            drop = lo < n_excl && excl[lo] == t;
+        }
+        if (drop) continue;
+        out_idx[q * k_keep + kept] = id;
+        out_dist[q * k_keep + kept] = in_dist[q * k_in + j];
+        ++kept;
+    }
+    for (; kept < k_keep; ++kept) {
+        out_idx[q * k_keep + kept] = -1;
+        out_dist[q * k_keep + kept] = __int_as_float(0x7fc00000);   // NaN, as pipeline.py:515
+    }
+}
+
 constexpr size_t knn_lds_bytes() { return sizeof(float) * (2 * KT_M * KT_LD + 2 * KT_N * KT_LD); }
 static_assert(KT_N * KS_LD <= 2 * KT_M * KT_LD + 2 * KT_N * KT_LD, "score tile must fit in the tile buffers");
 
@@ -1416,6 +1449,20 @@ int radad_topk_merge_f64(int metric, const double* in_key_dev, const int64_t* in
                          float* out_dist_dev, int64_t* out_idx_dev, double* out_key_dev, int device, void* stream) {
     return merge_lists<double>(metric, in_key_dev, in_idx_dev, n_parts, nq, k, out_dist_dev, out_idx_dev, out_key_dev, device,
                                stream);
+}
+
+int radad_filter_topk(const float* in_dist_dev, const int64_t* in_idx_dev, int64_t nq, int k_in, int k_keep,
+                      const int64_t* row_tags_dev, int64_t ntotal, int64_t id_base, const int64_t* excl_sorted_dev, int64_t n_excl,
+                      float* out_dist_dev, int64_t* out_idx_dev, int device, void* stream) {
+    RADAD_REQUIRE(nq >= 0 && k_in >= 0 && k_keep >= 1 && n_excl >= 0 && ntotal >= 0, "radad_filter_topk: bad shape");
+    if (nq == 0) return RADAD_OK;
+    RADAD_REQUIRE(out_dist_dev && out_idx_dev && (k_in == 0 || (in_dist_dev && in_idx_dev)), "radad_filter_topk: NULL buffer");
+    RADAD_REQUIRE(n_excl == 0 || (excl_sorted_dev && row_tags_dev), "radad_filter_topk: exclusion set without tags");
+    DeviceGuard g(device);
+    hipLaunchKernelGGL(k_filter_topk, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, (hipStream_t)stream, in_dist_dev, in_idx_dev,
+                       nq, k_in, k_keep, row_tags_dev, ntotal, id_base, excl_sorted_dev, n_excl, out_dist_dev, out_idx_dev);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
 }
 
 int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int device, void* stream) {

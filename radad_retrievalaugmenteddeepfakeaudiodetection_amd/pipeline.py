@@ -63,9 +63,10 @@ class HotPathPipeline:
     # ---- retrieve -----------------------------------------------------------------------------------------
     def retrieve_similar_vectors(self, query_vectors, query_paths: Optional[List[str]] = None, exclude_self: bool = True,
                                  return_info: bool = False, return_distances: bool = False):
-        """pipeline.py:449-532 with the same four return arities.  The search stays on the device; only the
-        [B, K+10] ids/distances come to the host for the basename exclusion (:491-509), and the kept neighbour
-        rows are gathered on the device in one launch instead of one index.reconstruct call each (:503)."""
+        """pipeline.py:449-532 with the same four return arities.  Search, basename exclusion (:491-509, through
+        per-row tags), compaction to K, label and neighbour-row gathers (:503) all stay on the device; nothing is
+        copied to the host unless `return_info` asks for the path strings.  Unfilled search slots (id -1) are skipped
+        instead of wrapping to vector_paths[-1] as the reference does (:495)."""
         import torch
         B = query_vectors.shape[0]
         K = int(self.config.top_k)
@@ -92,35 +93,27 @@ class HotPathPipeline:
         q = query_vectors.detach().to(self.device, torch.float32)
         try:
             dists_t, idxs_t = self.vector_db.search_batch(q, k=k_search)
-            dists, idxs = dists_t.cpu().numpy(), idxs_t.cpu().numpy()
-        except Exception:                                                       # pipeline.py:481-483
-            dists = np.zeros((B, 0), dtype=np.float32)
-            idxs = np.zeros((B, 0), dtype=np.int64)
+        except Exception:                                                       # pipeline.py:481-483: swallow, return padding
+            dists_t = idxs_t = None
 
-        paths_db, labels_db = self.vector_db.vector_paths, self.vector_db.vector_labels
-        train_ids = getattr(self, "training_file_ids", set())
-        chosen = np.full((B, K), -1, np.int64)
-        lbl = np.zeros((B, K), np.float32)
-        dist = np.full((B, K), np.nan, np.float32)
-        all_paths = []
-        for b in range(B):
-            n, row_paths = 0, []
-            for ii, dd in zip(idxs[b], dists[b]):
-                ii = int(ii)
-                if ii < 0:          # unfilled slot; the reference would wrap to vector_paths[-1] here (pipeline.py:495)
-                    continue
-                fname = os.path.basename(paths_db[ii])
-                if exclude_self:
-                    if query_paths is not None:
-                        if fname in exclude_ids:
-                            continue
-                    elif fname in train_ids:
-                        continue
-                chosen[b, n], lbl[b, n], dist[b, n] = ii, labels_db[ii], float(dd)
-                row_paths.append(paths_db[ii])
-                n += 1
-                if n == K:
-                    break
-            all_paths.append(row_paths + [""] * (K - n))                        # pipeline.py:511-515
-        vec_tensor = index.reconstruct_batch(torch.from_numpy(chosen).to(self.device))   # [B,K,D], zeros where id == -1
-        return pack(vec_tensor, torch.from_numpy(lbl).to(self.device), all_paths, torch.from_numpy(dist).to(self.device))
+        # exclusion + compaction + gathers on the device (csrc/knn.hip k_filter_topk, k_gather_rows): basenames are
+        # compared through their 63-bit tags, so the only per-row host work left is building the optional path lists
+        from .vector_database import path_tag
+        excl = None
+        if exclude_self:
+            names = exclude_ids if query_paths is not None else getattr(self, "training_file_ids", set())
+            if names:
+                excl = torch.tensor(sorted({path_tag(n) for n in names}), dtype=torch.int64, device=self.device)
+        if idxs_t is None:
+            idxs_t = torch.zeros((B, 0), dtype=torch.int64, device=self.device)
+            dists_t = torch.zeros((B, 0), dtype=torch.float32, device=self.device)
+        dist_t, chosen_t = self.vector_db.filter_hits(dists_t, idxs_t, K, excl)
+        valid = chosen_t >= 0
+        rows_t = (chosen_t - index.id_base).clamp(min=0)
+        lbl_t = torch.where(valid, self.vector_db.labels_device()[rows_t], torch.zeros((), device=self.device))   # 0.0 pad (:513)
+        all_paths = None
+        if return_info:
+            paths_db = self.vector_db.vector_paths
+            all_paths = [[paths_db[i - index.id_base] if i >= 0 else "" for i in row] for row in chosen_t.cpu().tolist()]
+        vec_tensor = index.reconstruct_batch(chosen_t)                          # [B,K,D], zeros where id == -1 (pipeline.py:512)
+        return pack(vec_tensor, lbl_t, all_paths, dist_t)

@@ -13,6 +13,7 @@ L2-normalised first when config.normalize_for_ip (default True) i.e. cosine (vec
 Device-resident variants (`search_device`, `reconstruct_batch`) let the pipeline skip the D2H/H2D hops.
 """
 import ctypes as C
+import hashlib
 import logging
 import os
 import pickle
@@ -21,6 +22,13 @@ from typing import Dict, List, Tuple
 import numpy as np
 
 from . import _lib
+
+
+def path_tag(path: str) -> int:
+    """Stable 63-bit tag of a file's basename: the device-side stand-in for the strings the reference compares in
+    retrieve_similar_vectors (pipeline.py:463,495-502)."""
+    h = hashlib.blake2b(os.path.basename(path).encode("utf-8", "surrogatepass"), digest_size=8).digest()
+    return int.from_bytes(h, "little") & 0x7FFFFFFFFFFFFFFF
 
 
 class HipFlatIndex:
@@ -153,6 +161,9 @@ class VectorDatabase:
         self.device_id = 0
         os.makedirs(config.vector_db_path, exist_ok=True)
         self._cosine = False
+        self._tags_host: List[int] = []      # path_tag of every stored row (device copy built lazily)
+        self._tags_dev = None
+        self._labels_dev = None
         import torch
         dev = torch.device(getattr(config, "device", "cuda"))
         if dev.type == "cuda":
@@ -193,6 +204,8 @@ class VectorDatabase:
                 else:
                     self.index.add(vectors[start:end])     # normalisation for cosine happens in the add kernel
                 added += end - start
+                self._tags_host.extend(path_tag(p) for p in paths[start:end])
+                self._tags_dev = self._labels_dev = None
                 self.vector_paths.extend(paths[start:end])
                 self.vector_labels.extend(labels[start:end])
                 for key, values in metadata.items():
@@ -230,6 +243,41 @@ class VectorDatabase:
         if is_dev:
             return self.index.search_device(query_vectors, k)
         return self.index.search(query_vectors.astype(np.float32, copy=False), k)
+
+    # ---- device-side columns for retrieve_similar_vectors ------------------------------------------------------
+    def row_tags_device(self):
+        """int64 [ntotal] CUDA tensor: path_tag(vector_paths[i])"""
+        import torch
+        if self._tags_dev is None or self._tags_dev.numel() != len(self.vector_paths):
+            if len(self._tags_host) != len(self.vector_paths):          # e.g. after load()
+                self._tags_host = [path_tag(p) for p in self.vector_paths]
+            self._tags_dev = torch.tensor(self._tags_host, dtype=torch.int64, device=torch.device("cuda", self.device_id))
+        return self._tags_dev
+
+    def labels_device(self):
+        """float32 [ntotal] CUDA tensor of vector_labels (the reference stacks them as float32, pipeline.py:523)"""
+        import torch
+        if self._labels_dev is None or self._labels_dev.numel() != len(self.vector_labels):
+            self._labels_dev = torch.tensor([float(l) for l in self.vector_labels], dtype=torch.float32,
+                                            device=torch.device("cuda", self.device_id))
+        return self._labels_dev
+
+    def filter_hits(self, dists, idxs, k_keep: int, exclude_tags=None):
+        """first k_keep hits per row whose tag is not excluded; (-1, NaN) padded.  All on the device."""
+        import torch
+        lib = _lib.load()
+        B, k_in = idxs.shape
+        out_d = torch.empty((B, k_keep), device=idxs.device, dtype=torch.float32)
+        out_i = torch.empty((B, k_keep), device=idxs.device, dtype=torch.int64)
+        n_excl = 0 if exclude_tags is None else int(exclude_tags.numel())
+        tags = self.row_tags_device() if n_excl else None
+        d, i = dists.contiguous().float(), idxs.contiguous()
+        with torch.cuda.device(idxs.device):
+            _lib.check(lib.radad_filter_topk(d.data_ptr(), i.data_ptr(), B, k_in, k_keep, tags.data_ptr() if n_excl else None,
+                                             self.index.ntotal, self.index.id_base, exclude_tags.data_ptr() if n_excl else None,
+                                             n_excl, out_d.data_ptr(), out_i.data_ptr(), idxs.device.index,
+                                             _lib.stream_ptr(idxs.device)), "radad_filter_topk")
+        return out_d, out_i
 
     # vector_database.py:185-188
     def search(self, query_vector, k: int = None):

@@ -210,3 +210,29 @@ def test_vector_database_surface(gpu, tmp_path):
     cfg.vector_db_index_type = "bogus"
     with pytest.raises(ValueError):
         R.VectorDatabase(cfg).create_index(8)                   # vector_database.py:72
+
+
+def test_filter_topk_kernel(gpu, tmp_path):
+    """radad_filter_topk == the exclusion loop of pipeline.py:491-515 on ids"""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.vector_database import path_tag
+    cfg = R.Config()
+    cfg.update(device=gpu, vector_db_path=str(tmp_path / "v"))
+    vdb = R.VectorDatabase(cfg)
+    n = 50
+    paths = [f"/a/b/f{i % 40}.wav" for i in range(n)]          # f0..f9 appear twice: duplicates of a basename share a tag
+    vdb.add_vectors(synth.rows(0, n, 32, 3), paths, [i % 2 for i in range(n)], {})
+    assert vdb.row_tags_device().cpu().tolist() == [path_tag(p) for p in paths]
+    assert path_tag("/x/y/f3.wav") == path_tag("f3.wav") != path_tag("f4.wav")
+    idxs = torch.tensor([[3, 43, 7, -1, 9, 12], [0, 1, 2, 3, 4, 5], [40, 41, 42, 43, 44, 45]], device=gpu)
+    dists = torch.arange(18, dtype=torch.float32, device=gpu).reshape(3, 6)
+    excl = torch.tensor(sorted({path_tag("f3.wav"), path_tag("f9.wav"), path_tag("f1.wav")}), device=gpu)
+    d, i = vdb.filter_hits(dists, idxs, 3, excl)
+    assert i.cpu().tolist() == [[7, 12, -1], [0, 2, 4], [40, 42, 44]]          # row 43 is f3.wav again; -1 is skipped
+    dd = d.cpu().numpy()
+    assert dd[0, 0] == 2 and dd[0, 1] == 5 and np.isnan(dd[0, 2]) and dd[1].tolist() == [6, 8, 10]
+    d, i = vdb.filter_hits(dists, idxs, 4, None)                                # no exclusion set
+    assert i.cpu().tolist()[0] == [3, 43, 7, 9]
+    d, i = vdb.filter_hits(dists[:, :0], idxs[:, :0], 2, excl)                  # no hits at all -> padding
+    assert i.cpu().tolist() == [[-1, -1]] * 3 and bool(torch.isnan(d).all())
