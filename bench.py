@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU per step")
     ap.add_argument("--db-rows", type=int, default=DB_ROWS, help="total reference-store rows")
     ap.add_argument("--cpu-sample", type=int, default=192, help="clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--store-dtype", choices=["f32", "f16"], default="f32",
+                    help="f16 = the reference's use_float16 knob (fp16 rows, fp16 MFMA scan); NOT the headline configuration")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,7 +84,8 @@ def main():
     lib = _lib.load()
 
     cfg = R.Config()
-    cfg.update(device=dev, tpp_levels=[1], tpp_pooling_type="max", feature_dim=DIM, vector_db_index_type="IP")
+    cfg.update(device=dev, tpp_levels=[1], tpp_pooling_type="max", feature_dim=DIM, vector_db_index_type="IP",
+               use_float16=(args.store_dtype == "f16"))
     fe = R.MelProjectionFeatureExtractor(cfg)
     B = args.clips
     n_total = args.db_rows
@@ -163,18 +166,23 @@ def main():
     flops = 2.0 * Q * (hi - lo) * DIM                                   # algorithmic FLOPs of one scan launch
     alg_bytes = 4.0 * (hi - lo) * DIM + 4.0 * Q * DIM + 12.0 * Q * TOP_K
     achieved = flops / (knn_avg * 1e-3) / 1e12
+    f16 = args.store_dtype == "f16"
+    peak = 2500.0 if f16 else PEAK_MFMA_F32_TFLOPS           # dense fp16 MFMA ~2.5 PFLOP/s (MI355X_MICROARCH.md)
+    if f16:
+        alg_bytes = 2.0 * (hi - lo) * DIM + 2.0 * Q * DIM + 12.0 * Q * TOP_K
     out = {
         "metric": "clips/sec (segment+embed+retrieve) @1Mx512 DB",
         "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.store_dtype == "f32" else "f32 embed; f16 store + f16 MFMA scan (f32 accumulate, f64 re-rank)",
+        "data": "synthetic",
         "config": {"workload": f"{B} clips/GPU x 4 s @16 kHz (3 segments), F=512, levels=[1], cosine top-{TOP_K}, "
                                f"{n_total} x {DIM} fp32 store row-sharded over {world} GPU(s)",
                    "clips_per_gpu": B, "db_rows": n_total, "dim": DIM, "k": TOP_K, "parallelism": f"shard{world}",
                    "planted_neighbours_found": planted_ok},
-        "roofline": {"kernel": "k_knn_f32", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_MFMA_F32_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_F32_TFLOPS, 4),
-                     "traffic": SCAN_TRAFFIC_BYTES_R1B if (world == 1 and B == CLIPS_PER_GPU and n_total == DB_ROWS) else None,
+        "roofline": {"kernel": "k_knn_f32_reg<16,%s>" % ("true" if f16 else "false"), "bound": "mfma", "achieved": round(achieved, 2),
+                     "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                     "traffic": SCAN_TRAFFIC_BYTES_R1B if (world == 1 and B == CLIPS_PER_GPU and n_total == DB_ROWS and not f16) else None,
                      "kernel_ms": round(knn_avg, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
                      "hbm_GBps_algorithmic": round(alg_bytes / (knn_avg * 1e-3) / 1e9, 1),
                      "launch": vdb.index.last_launch()},
@@ -201,11 +209,14 @@ def main():
         # retrieve parity proper (untimed): the reference normalises in float32 BEFORE the index sees the vectors
         # (vector_database.py:103-104,118,166), so the search is judged on the rows and queries as stored --
         # float64 inner products of exactly those float32 vectors, (distance, id) order.
-        rn, qn = torch.empty_like(rows), torch.empty_like(emb[:ns])
-        _lib.check(lib.radad_rownorm(rows.data_ptr(), rn.data_ptr(), rows.shape[0], DIM, local_rank, _lib.stream_ptr(dev)))
+        qn = torch.empty_like(emb[:ns])
         _lib.check(lib.radad_rownorm(emb[:ns].contiguous().data_ptr(), qn.data_ptr(), ns, DIM, local_rank, _lib.stream_ptr(dev)))
-        sd, si = O.knn(rn.cpu().numpy(), qn.cpu().numpy(), TOP_K, "IP", chunk=65536)
-        del rn
+        stored = np.empty((hi - lo, DIM), np.float32)             # the rows exactly as the store holds them (decoded)
+        for r0 in range(0, hi - lo, 131072):
+            ids = torch.arange(lo + r0, min(hi, lo + r0 + 131072), device=dev)
+            stored[r0:r0 + len(ids)] = vdb.index.reconstruct_batch(ids).cpu().numpy()
+        sd, si = O.knn(stored, qn.cpu().numpy(), TOP_K, "IP", chunk=65536)
+        del stored
         ids_equal = bool(np.array_equal(I_h, si))
         dist_err = float(np.abs(D_h - sd).max())
         norm_err = float(np.abs(qn.cpu().numpy().astype(np.float64) - O.maybe_normalize(emb_gpu, True)).max())

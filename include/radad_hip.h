@@ -63,6 +63,14 @@ typedef struct radad_knn_s* radad_knn_t;
 /* dim must be a positive multiple of 4.  id_base is added to every returned index (row-shard offset;
  * 0 for an unsharded store).  Rows are stored as fp32 in HBM in insertion order. */
 int radad_knn_create(int dim, int metric, int device, int64_t id_base, radad_knn_t* out);
+/* same with a choice of storage type.  RADAD_STORE_F16 is the reference's `use_float16` knob (faiss
+ * GpuIndexFlatConfig.useFloat16, vector_database.py:80): rows are rounded to IEEE fp16 on the way in (after the cosine
+ * normalisation), the scan runs on v_mfma_f32_32x32x16_f16 (fp16 operands, fp32 accumulate; dim % 64 == 0 and k <= 26,
+ * other shapes decode to fp32 while staging), the float64 re-rank uses the fp32 queries against the decoded rows,
+ * reconstruct returns the decoded rows. */
+#define RADAD_STORE_F32 0
+#define RADAD_STORE_F16 1
+int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_t id_base, radad_knn_t* out);
 int radad_knn_destroy(radad_knn_t h);
 int radad_knn_dim(radad_knn_t h, int* dim);
 int radad_knn_metric(radad_knn_t h, int* metric);

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libradad_hip.so")
 RADAD_OK, RADAD_EINVAL, RADAD_EHIP, RADAD_ENOMEM, RADAD_EIO, RADAD_ESTATE = 0, -1, -2, -3, -4, -5
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
 POOL_MAX, POOL_AVG = 0, 1
+STORE_F32, STORE_F16 = 0, 1
 MAX_LEVELS = 8
 KNN_MAX_K = 1024
 
@@ -38,6 +39,7 @@ SIGNATURES = {
     "radad_last_error": (C.c_char_p, []),
     "radad_device_count": (C.c_int, []),
     "radad_knn_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
+    "radad_knn_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
     "radad_knn_destroy": (C.c_int, [C.c_void_p]),
     "radad_knn_dim": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_metric": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),

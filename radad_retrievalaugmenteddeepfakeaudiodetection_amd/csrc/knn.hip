@@ -35,9 +35,10 @@ constexpr int KS_LD = KT_M + 4;  // score-tile row (floats): 132-dword stride ke
 constexpr int IDX_SENTINEL = 0x7fffffff;
 
 struct KnnParams {
-    const float* db;      // [n, dim]
+    const void* db;       // [n, dim] fp32, or fp16 when db_f16
     const float* ynorm;   // [n] (L2) or nullptr
-    const float* q;       // [nq, dim] (already normalised for cosine)
+    const void* q;        // [nq, dim] (already normalised for cosine); fp16 for the fp16 tile kernel, fp32 otherwise
+    int db_f16;
     int64_t n;
     int nq;
     int dim;
@@ -56,6 +57,8 @@ __device__ __forceinline__ bool better(float s, int i, float ws, int wi) {
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // One 128 x 128 tile of S = Y . Q^T over the full depth: acc[mt][nt] (wave sub-tile 64 x 64 as 2 x 2 MFMA 32x32 blocks).
 // Global -> LDS staging uses buffer loads: the descriptors are wave-uniform (SGPRs), rows past the end of the
@@ -68,6 +71,7 @@ struct TileCtx {
     int wm, wn, l31, lh;
 };
 
+template <bool A_F16>
 __device__ __forceinline__ void knn_tile_gemm(const TileCtx& c, __amdgpu_buffer_rsrc_t ra_desc, __amdgpu_buffer_rsrc_t rq_desc,
                                               float* sA, float* sB, f32x16 (&acc)[2][2]) {
     f32x4 ra[4], rb[4];
@@ -79,7 +83,14 @@ __device__ __forceinline__ void knn_tile_gemm(const TileCtx& c, __amdgpu_buffer_
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned vo = kin ? c.voff[i] : 0x7FFF0000u;
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_desc, vo, soff, 0));
+            if (A_F16) {      // fp16 store: 4 halfs per lane, decoded to fp32 on the way to LDS (exact)
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 hv = __builtin_amdgcn_raw_buffer_load_b64(ra_desc, kin ? (c.voff[i] >> 1) : 0x7FFF0000u, soff >> 1, 0);
+                const f16x4 h4 = __builtin_bit_cast(f16x4, hv);
+                ra[i] = f32x4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+            } else {
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra_desc, vo, soff, 0));
+            }
             rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rq_desc, vo, soff, 0));
         }
     };
@@ -220,9 +231,9 @@ struct DmaCtx {
     unsigned rd_x;           // (lh ^ swizzle) << 4: XOR-ed with 32*kk gives the chunk offset inside the row
 };
 
-__device__ __forceinline__ DmaCtx make_dma_ctx(int dim, int tid, int debug) {
+__device__ __forceinline__ DmaCtx make_dma_ctx(int dim, int tid, int debug, int esize) {
     DmaCtx c;
-    c.dim = dim; c.nk = (dim + KT_K - 1) / KT_K; c.debug = debug;
+    c.dim = dim; c.nk = (dim * esize + KD_ROW_BYTES - 1) / KD_ROW_BYTES; c.debug = debug;   // 128 bytes of every row per K step
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
@@ -231,7 +242,7 @@ __device__ __forceinline__ DmaCtx make_dma_ctx(int dim, int tid, int debug) {
         const int r = grp * 8 + (lane >> 3);
         const int pc = lane & 7;                      // physical chunk this lane fills
         const int lc = pc ^ ((r >> 1) & 7);           // logical chunk it must fetch
-        c.voff[i] = (unsigned)((r * dim + lc * 4) * (int)sizeof(float));
+        c.voff[i] = (unsigned)(r * dim * esize + lc * 16);
         c.dst[i] = (unsigned)(grp * 1024);
     }
     const int l31 = lane & 31, lh = lane >> 5;
@@ -253,7 +264,7 @@ __device__ __forceinline__ void dma_issue(const DmaCtx& c, __amdgpu_buffer_rsrc_
     }
 }
 
-template <typename Hook>
+template <bool F16, typename Hook>
 __device__ __forceinline__ void knn_tile_gemm_dma(const DmaCtx& c, __amdgpu_buffer_rsrc_t cur_desc, __amdgpu_buffer_rsrc_t next_desc,
                                                   bool has_next, __amdgpu_buffer_rsrc_t q_desc, char* sA, char* sB, int& gbuf,
                                                   f32x16 (&acc)[2][2], Hook&& after_first_barrier) {
@@ -278,12 +289,23 @@ __device__ __forceinline__ void knn_tile_gemm_dma(const DmaCtx& c, __amdgpu_buff
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(a_row + 32 * KD_ROW_BYTES + off);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(b_row + off);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(b_row + 32 * KD_ROW_BYTES + off);
+            if constexpr (F16) {
+                // the same 16 bytes are 8 halfs: k = 16kk + 8lh + j of the row -- exactly the A/B lane map of
+                // v_mfma_f32_32x32x16_f16, so one MFMA (16x the fp32 rate) replaces the four below
+                const f16x8 ha0 = __builtin_bit_cast(f16x8, a0), ha1 = __builtin_bit_cast(f16x8, a1);
+                const f16x8 hb0 = __builtin_bit_cast(f16x8, b0), hb1 = __builtin_bit_cast(f16x8, b1);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha0, hb0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha0, hb1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha1, hb0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ha1, hb1, acc[1][1], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+                }
             }
         }
         if (!(c.debug & 8)) __syncthreads();      // waits vmcnt(0): the DMA issued above has landed for everyone
@@ -306,10 +328,11 @@ __device__ __forceinline__ TileCtx make_tile_ctx(int dim, int tid) {
     return c;
 }
 // descriptor over `rows` rows of `dim` floats starting at `base` (wave-uniform inputs only)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_desc(const float* base, int rows, int dim) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, rows * dim * (int)sizeof(float), 0x00020000);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_desc(const void* base, int rows, int dim, int esize = 4) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, rows * dim * esize, 0x00020000);
 }
 
+template <bool A_F16>
 __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32(KnnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* sA = reinterpret_cast<float*>(smem);          // [2][KT_M][KT_LD]
@@ -351,11 +374,14 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32(KnnParams p) {
     if (chunk_begin >= chunk_end) return;
 
     const TileCtx tc = make_tile_ctx(p.dim, tid);
-    const __amdgpu_buffer_rsrc_t q_desc = rows_desc(p.q + (int64_t)q0 * p.dim, min(KT_N, p.nq - q0), p.dim);
+    const __amdgpu_buffer_rsrc_t q_desc =
+        rows_desc(reinterpret_cast<const float*>(p.q) + (int64_t)q0 * p.dim, min(KT_N, p.nq - q0), p.dim);
+    constexpr int AES = A_F16 ? 2 : 4;      // bytes per stored element
 
     for (int64_t row0 = chunk_begin; row0 < chunk_end; row0 += KT_M) {
         f32x16 acc[2][2];
-        knn_tile_gemm(tc, rows_desc(p.db + row0 * p.dim, (int)min((int64_t)KT_M, chunk_end - row0), p.dim), q_desc, sA, sB, acc);
+        knn_tile_gemm<A_F16>(tc, rows_desc(reinterpret_cast<const char*>(p.db) + row0 * p.dim * AES,
+                                           (int)min((int64_t)KT_M, chunk_end - row0), p.dim, AES), q_desc, sA, sB, acc);
 
         // ---- fused top-k epilogue -------------------------------------------------------------
         // acc[mt][nt][r] = dot(store row row0 + wm*64 + mt*32 + (r&3) + 8*(r>>2) + 4*lh,
@@ -450,8 +476,9 @@ __device__ __forceinline__ void list_insert(u64 (&l)[KSEL], u64 key) {
     l[0] = key > l[0] ? key : l[0];
 }
 
-template <int KSEL>
+template <int KSEL, bool F16>
 __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
+    constexpr int ES = F16 ? 2 : 4;          // bytes per element of BOTH operands (fp16 store is scanned with fp16 queries)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* sA = smem;                                                  // [2][128 rows][128 B], swizzled
     char* sB = smem + 2 * KD_TILE_BYTES;                              // [2][128 rows][128 B], swizzled
@@ -487,13 +514,15 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
     if (tid == 0) *s_flag = 0;
     __syncthreads();
 
-    const DmaCtx dc = make_dma_ctx(p.dim, tid, p.debug);
-    const __amdgpu_buffer_rsrc_t q_desc = rows_desc(p.q + (int64_t)q0 * p.dim, min(KT_N, p.nq - q0), p.dim);
+    const DmaCtx dc = make_dma_ctx(p.dim, tid, p.debug, ES);
+    const __amdgpu_buffer_rsrc_t q_desc =
+        rows_desc(reinterpret_cast<const char*>(p.q) + (int64_t)q0 * p.dim * ES, min(KT_N, p.nq - q0), p.dim, ES);
     const int ql[2] = {wn * 64 + l31, wn * 64 + 32 + l31};
     const bool qvalid[2] = {q0 + ql[0] < p.nq, q0 + ql[1] < p.nq};
 
     auto tile_desc = [&](int64_t r0) {
-        return rows_desc(p.db + r0 * p.dim, (int)max((int64_t)0, min((int64_t)KT_M, chunk_end - r0)), p.dim);
+        return rows_desc(reinterpret_cast<const char*>(p.db) + r0 * p.dim * ES,
+                         (int)max((int64_t)0, min((int64_t)KT_M, chunk_end - r0)), p.dim, ES);
     };
     int gbuf = 0;
     if (chunk_begin < chunk_end) {
@@ -519,7 +548,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
     for (int64_t row0 = chunk_begin; row0 < chunk_end; row0 += KT_M) {
         f32x16 acc[2][2];
         const bool has_next = row0 + KT_M < chunk_end;
-        knn_tile_gemm_dma(dc, tile_desc(row0), tile_desc(row0 + KT_M), has_next, q_desc, sA, sB, gbuf, acc,
+        knn_tile_gemm_dma<F16>(dc, tile_desc(row0), tile_desc(row0 + KT_M), has_next, q_desc, sA, sB, gbuf, acc,
                           [&]() { if (pending) { drain(); pending = false; } });
         if (p.debug & 1) {      // timing experiment: keep the accumulators alive, skip the epilogue
             if (acc[0][0][0] + acc[0][1][5] + acc[1][0][9] + acc[1][1][15] == 12345.678f) s_thr[tid & 127] = 1.f;
@@ -628,7 +657,7 @@ constexpr int SQ_SLOTS = 16;
 constexpr int SQ_MAX_DIM = 2048;
 
 struct SmallQParams {
-    const float* db; const float* ynorm; const float* q;
+    const float* db; const float* ynorm; const float* q;      // fp32 store only
     int64_t n;
     int nq, dim, k, l2;
     int rows_per_wave;          // multiple of 16
@@ -770,8 +799,9 @@ struct RefineParams {
     const int* idx;           // [nq, n_parts, ksel] local row or IDX_SENTINEL
     int n_parts, ksel, k, dim, l2;
     int64_t nq;
-    const float* db;          // stored rows (normalised for cosine)
-    const float* q;           // the queries the scan used (normalised for cosine)
+    const void* db;           // stored rows (normalised for cosine); fp16 when db_f16
+    int db_f16;
+    const float* q;           // the fp32 queries (normalised for cosine)
     int64_t id_base;
     float* out_dist;          // [nq, k]
     int64_t* out_idx;         // [nq, k]
@@ -822,11 +852,16 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
     // 2) float64 re-score of the survivors
     const float* qrow = p.q + q * p.dim;
     for (int c = 0; c < nsel; ++c) {
-        const float* y = p.db + (int64_t)c_id[c] * p.dim;
         double acc = 0.0;
         for (int i = lane * 4; i < p.dim; i += 256) {
             const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + i);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(y + i);
+            f32x4 b;
+            if (p.db_f16) {
+                const f16x4 h4 = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.db) + (int64_t)c_id[c] * p.dim + i);
+                b = f32x4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+            } else {
+                b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.db) + (int64_t)c_id[c] * p.dim + i);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (p.l2) { const double d = (double)a[e] - (double)b[e]; acc += d * d; }
@@ -912,17 +947,29 @@ __global__ __launch_bounds__(256) void k_merge_lists(ListMergeParams<KeyT> p) {
 
 // ---- append path ----------------------------------------------------------------------------------
 // one wave per row.  mode 0: copy; 1: copy + ynorm = sum x^2; 2: x / (sqrt(sum x^2) + 1e-12)
-__global__ __launch_bounds__(256) void k_rows_prepare(const float* in, float* out, float* ynorm, int64_t n, int dim, int mode) {
+// OutT = float: as above.  OutT = _Float16 (fp16 store / fp16 scan queries): values are rounded to nearest-even on the
+// way out and |y|^2 is taken of the ROUNDED row, so the L2 score 2 q.y - |y|^2 is consistent with what is stored.
+template <typename OutT>
+__global__ __launch_bounds__(256) void k_rows_prepare(const float* in, OutT* out, float* ynorm, int64_t n, int dim, int mode) {
+    constexpr bool H = sizeof(OutT) == 2;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     const f32x4* src = reinterpret_cast<const f32x4*>(in + row * dim);
-    f32x4* dst = reinterpret_cast<f32x4*>(out + row * dim);
     const int nv = dim >> 2;
+    auto put = [&](int i, f32x4 v) {
+        if constexpr (H) {
+            const f16x4 h4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            reinterpret_cast<f16x4*>(out + row * dim)[i] = h4;
+        } else {
+            reinterpret_cast<f32x4*>(out + row * dim)[i] = v;
+        }
+    };
     float ss = 0.f;
     if (mode != 0) {
         for (int i = lane; i < nv; i += 64) {
-            const f32x4 v = src[i];
+            f32x4 v = src[i];
+            if (H && mode == 1) { v[0] = (float)(_Float16)v[0]; v[1] = (float)(_Float16)v[1]; v[2] = (float)(_Float16)v[2]; v[3] = (float)(_Float16)v[3]; }
             ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         }
         ss = wave_sum(ss);
@@ -932,16 +979,17 @@ __global__ __launch_bounds__(256) void k_rows_prepare(const float* in, float* ou
         for (int i = lane; i < nv; i += 64) {
             f32x4 v = src[i];
             v[0] = v[0] / den; v[1] = v[1] / den; v[2] = v[2] / den; v[3] = v[3] / den;
-            dst[i] = v;
+            put(i, v);
         }
     } else {
-        if (in != out)
-            for (int i = lane; i < nv; i += 64) dst[i] = src[i];
+        if (H || reinterpret_cast<const void*>(in) != reinterpret_cast<const void*>(out))
+            for (int i = lane; i < nv; i += 64) put(i, src[i]);
         if (mode == 1 && lane == 0) ynorm[row] = ss;
     }
 }
 
-__global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ db, const int64_t* __restrict__ idx,
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_rows(const T* __restrict__ db, const int64_t* __restrict__ idx,
                                                      int64_t n_out, int64_t ntotal, int64_t id_base, int dim,
                                                      float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -950,9 +998,32 @@ __global__ __launch_bounds__(256) void k_gather_rows(const float* __restrict__ d
     const int64_t r = idx[o] - id_base;
     const bool ok = idx[o] >= 0 && r >= 0 && r < ntotal;
     f32x4* dst = reinterpret_cast<f32x4*>(out + o * dim);
-    const f32x4* src = reinterpret_cast<const f32x4*>(db + (ok ? r : 0) * dim);
+    const T* src = db + (ok ? r : 0) * dim;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    for (int i = lane; i < (dim >> 2); i += 64) dst[i] = ok ? src[i] : z;
+    for (int i = lane; i < (dim >> 2); i += 64) {
+        f32x4 v = z;
+        if (ok) {
+            if constexpr (sizeof(T) == 2) {
+                const f16x4 h4 = reinterpret_cast<const f16x4*>(src)[i];
+                v = f32x4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};       // fp16 -> fp32 is exact
+            } else {
+                v = reinterpret_cast<const f32x4*>(src)[i];
+            }
+        }
+        dst[i] = v;
+    }
+}
+
+// |y|^2 of stored rows (fp32 or fp16): used when a snapshot is loaded into an L2 store
+template <typename T>
+__global__ __launch_bounds__(256) void k_row_sqnorm(const T* __restrict__ rows, int64_t n, int dim, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float ss = 0.f;
+    for (int i = lane; i < dim; i += 64) { const float v = (float)rows[r * dim + i]; ss += v * v; }
+    ss = wave_sum(ss);
+    if (lane == 0) out[r] = ss;
 }
 
 // exclusion + compaction of search hits (retrieve_similar_vectors, pipeline.py:491-515): one thread per query row
@@ -1015,8 +1086,11 @@ struct radad_knn_s {
     int dim = 0, metric = 0, device = 0;
     int64_t id_base = 0;
     int64_t ntotal = 0, capacity = 0;
-    float* rows = nullptr;
+    int f16 = 0;              // 1: rows are stored as IEEE fp16 (config.use_float16, vector_database.py:80)
+    char* rows = nullptr;     // [capacity, dim] fp32 or fp16
     float* ynorm = nullptr;
+    size_t esize() const { return f16 ? 2 : 4; }
+    size_t row_bytes() const { return (size_t)dim * esize(); }
     // search workspace (grown on demand, reused)
     void* ws = nullptr;
     size_t ws_bytes = 0;
@@ -1026,9 +1100,9 @@ struct radad_knn_s {
 };
 
 static int knn_realloc(radad_knn_t h, int64_t cap) {
-    float* nrows = nullptr;
+    char* nrows = nullptr;
     float* nnorm = nullptr;
-    if (hipMalloc(&nrows, (size_t)cap * h->dim * sizeof(float)) != hipSuccess) {
+    if (hipMalloc(&nrows, (size_t)cap * h->row_bytes()) != hipSuccess) {
         radad_set_error("hipMalloc of %lld x %d rows failed", (long long)cap, h->dim);
         return RADAD_ENOMEM;
     }
@@ -1038,7 +1112,7 @@ static int knn_realloc(radad_knn_t h, int64_t cap) {
         return RADAD_ENOMEM;
     }
     if (h->ntotal > 0) {
-        RADAD_HIP_CHECK(hipMemcpy(nrows, h->rows, (size_t)h->ntotal * h->dim * sizeof(float), hipMemcpyDeviceToDevice));
+        RADAD_HIP_CHECK(hipMemcpy(nrows, h->rows, (size_t)h->ntotal * h->row_bytes(), hipMemcpyDeviceToDevice));
         if (nnorm) RADAD_HIP_CHECK(hipMemcpy(nnorm, h->ynorm, (size_t)h->ntotal * sizeof(float), hipMemcpyDeviceToDevice));
     }
     if (h->rows) (void)hipFree(h->rows);
@@ -1072,7 +1146,12 @@ static int knn_workspace(radad_knn_t h, size_t bytes) {
 extern "C" {
 
 int radad_knn_create(int dim, int metric, int device, int64_t id_base, radad_knn_t* out) {
+    return radad_knn_create_ex(dim, metric, RADAD_STORE_F32, device, id_base, out);
+}
+
+int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_t id_base, radad_knn_t* out) {
     RADAD_REQUIRE(out != nullptr, "radad_knn_create: out is NULL");
+    RADAD_REQUIRE(store_dtype == RADAD_STORE_F32 || store_dtype == RADAD_STORE_F16, "radad_knn_create: unsupported store dtype %d", store_dtype);
     RADAD_REQUIRE(dim > 0 && (dim % 4) == 0, "radad_knn_create: dim must be a positive multiple of 4 (got %d)", dim);
     RADAD_REQUIRE(metric >= 0 && metric <= 2, "radad_knn_create: unsupported metric %d", metric);
     int ndev = 0;
@@ -1080,7 +1159,7 @@ int radad_knn_create(int dim, int metric, int device, int64_t id_base, radad_knn
     RADAD_REQUIRE(device >= 0 && device < ndev, "radad_knn_create: device %d not in [0,%d)", device, ndev);
     radad_knn_s* h = new (std::nothrow) radad_knn_s();
     if (!h) { radad_set_error("out of host memory"); return RADAD_ENOMEM; }
-    h->dim = dim; h->metric = metric; h->device = device; h->id_base = id_base;
+    h->dim = dim; h->metric = metric; h->device = device; h->id_base = id_base; h->f16 = store_dtype == RADAD_STORE_F16;
     *out = h;
     return RADAD_OK;
 }
@@ -1126,10 +1205,11 @@ int radad_knn_add(radad_knn_t h, const float* rows_dev, int64_t n, void* stream)
         if (rc) return rc;
     }
     const int mode = h->metric == RADAD_METRIC_COSINE ? 2 : (h->metric == RADAD_METRIC_L2 ? 1 : 0);
-    float* dst = h->rows + h->ntotal * h->dim;
+    char* dst = h->rows + (size_t)h->ntotal * h->row_bytes();
     float* yn = h->ynorm ? h->ynorm + h->ntotal : nullptr;
     const unsigned grid = (unsigned)ceil_div64(n, 4);
-    hipLaunchKernelGGL(k_rows_prepare, dim3(grid), dim3(256), 0, st, rows_dev, dst, yn, n, h->dim, mode);
+    if (h->f16) hipLaunchKernelGGL(k_rows_prepare<_Float16>, dim3(grid), dim3(256), 0, st, rows_dev, (_Float16*)dst, yn, n, h->dim, mode);
+    else hipLaunchKernelGGL(k_rows_prepare<float>, dim3(grid), dim3(256), 0, st, rows_dev, (float*)dst, yn, n, h->dim, mode);
     RADAD_HIP_CHECK(hipGetLastError());
     h->ntotal += n;
     return RADAD_OK;
@@ -1191,7 +1271,7 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     int64_t chunk_rows;
     knn_geometry(std::max<int64_t>(h->ntotal, 1), nq, &n_qtiles, &n_splits, &chunk_rows);
     // small batches (the online predict case) take the HBM-bound streaming kernel: one list per WAVE
-    const bool smallq = nq <= SQ_NQ && h->dim % 32 == 0 && h->dim <= SQ_MAX_DIM && k + KNN_MARGIN <= 32 && h->ntotal > 0;
+    const bool smallq = !h->f16 && nq <= SQ_NQ && h->dim % 32 == 0 && h->dim <= SQ_MAX_DIM && k + KNN_MARGIN <= 32 && h->ntotal > 0;
     int sq_rows_per_wave = 0;
     if (smallq) {
         const int64_t waves_wanted = 256 * 8;                                     // 8 waves (2 workgroups) per CU
@@ -1204,11 +1284,10 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     h->last_qtiles = n_qtiles;
     h->last_splits = n_splits;
 
-    // workspace: [qn: nq*dim] (cosine) | [qnorm: nq] (L2) | part_score | part_idx
+    // workspace: [qn: nq*dim fp32] (cosine) | [qh: nq*dim fp16] (fp16 store) | part_score | part_idx
     const size_t qn_bytes = h->metric == RADAD_METRIC_COSINE ? (size_t)nq * h->dim * sizeof(float) : 0;
-    const size_t qnorm_bytes = (((size_t)nq * sizeof(float)) + 255) & ~(size_t)255;
-    const int ksel = k + KNN_MARGIN;             // the scan keeps a few spare candidates for the float64 re-rank
-    const size_t part_elems = (size_t)nq * n_splits * ksel;
+    const size_t qnorm_bytes = h->f16 ? ((((size_t)nq * h->dim * 2) + 255) & ~(size_t)255) : 256;
+    const size_t part_elems = (size_t)nq * n_splits * (k + KNN_MARGIN);
     const size_t off_qnorm = (qn_bytes + 255) & ~(size_t)255;
     const size_t off_ps = off_qnorm + qnorm_bytes;
     const size_t off_pi = off_ps + ((part_elems * sizeof(float) + 255) & ~(size_t)255);
@@ -1220,21 +1299,27 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     }
     char* ws = (char*)h->ws;
     float* qn = (float*)ws;
-    float* qnorm = (float*)(ws + off_qnorm);
+    _Float16* qh = (_Float16*)(ws + off_qnorm);
     float* ps = (float*)(ws + off_ps);
     int* pi = (int*)(ws + off_pi);
 
     const float* q_use = q_dev;
     const unsigned rgrid = (unsigned)ceil_div64(nq, 4);
     if (h->metric == RADAD_METRIC_COSINE) {
-        hipLaunchKernelGGL(k_rows_prepare, dim3(rgrid), dim3(256), 0, st, q_dev, qn, (float*)nullptr, nq, h->dim, 2);
+        hipLaunchKernelGGL(k_rows_prepare<float>, dim3(rgrid), dim3(256), 0, st, q_dev, qn, (float*)nullptr, nq, h->dim, 2);
         q_use = qn;
     }
-    (void)qnorm;   // |q|^2 is not needed: ranking uses 2 q.y - |y|^2 and the reported distance is re-scored exactly
+    // (|q|^2 is not needed: ranking uses 2 q.y - |y|^2 and the reported distance is re-scored exactly)
+    // fp16 store + DMA tile kernel: the scan multiplies fp16 x fp16 (fp32 accumulate), so it gets an fp16 copy of the
+    // (normalised) queries; the float64 re-rank below still uses the fp32 queries against the decoded rows.
+    const int ksel = k + KNN_MARGIN;             // the scan keeps a few spare candidates for the float64 re-rank
+    const bool f16_tile = h->f16 && ksel <= 32 && h->dim % 64 == 0;
+    if (f16_tile)
+        hipLaunchKernelGGL(k_rows_prepare<_Float16>, dim3(rgrid), dim3(256), 0, st, q_use, qh, (float*)nullptr, nq, h->dim, 0);
     RADAD_HIP_CHECK(hipGetLastError());
 
     KnnParams p;
-    p.db = h->rows; p.ynorm = h->ynorm; p.q = q_use; p.n = h->ntotal; p.nq = (int)nq; p.dim = h->dim; p.k = ksel;
+    p.db = h->rows; p.db_f16 = h->f16; p.ynorm = h->ynorm; p.q = f16_tile ? (const void*)qh : (const void*)q_use; p.n = h->ntotal; p.nq = (int)nq; p.dim = h->dim; p.k = ksel;
     p.l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0;
     p.n_qtiles = n_qtiles; p.n_splits = n_splits; p.chunk_rows = chunk_rows; p.part_score = ps; p.part_idx = pi;
     { const char* dbg = getenv("RADAD_DEBUG_KNN"); p.debug = dbg ? atoi(dbg) : 0; }
@@ -1243,7 +1328,7 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     const dim3 grid((unsigned)(n_qtiles * n_splits));
     if (smallq) {
         SmallQParams sp;
-        sp.db = h->rows; sp.ynorm = h->ynorm; sp.q = q_use; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel;
+        sp.db = (const float*)h->rows; sp.ynorm = h->ynorm; sp.q = q_use; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel;
         sp.l2 = p.l2; sp.rows_per_wave = sq_rows_per_wave; sp.n_parts = n_splits; sp.part_score = ps; sp.part_idx = pi;
         const size_t slot_bytes = std::max<size_t>(sizeof(float2) * 4 * SQ_NQ * SQ_SLOTS, sizeof(u64) * 3 * SQ_NQ * 32);
         const size_t lds = sizeof(float) * SQ_NQ * (h->dim + 4) + slot_bytes + sizeof(int) * 4 * SQ_NQ;
@@ -1261,30 +1346,34 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
             hipLaunchKernelGGL(k_knn_f32_smallq<32>, sgrid, dim3(SQ_THREADS), lds, st, sp);
             h->prof.end(st);
         }
-    } else if (ksel <= 16 && h->dim % KT_K == 0) {
-        RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32_reg<16>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_reg_lds_bytes()));
+    } else if (f16_tile || (!h->f16 && ksel <= 32 && h->dim % KT_K == 0)) {
+        // tile kernel with LDS-DMA staging and register-resident lists: <list entries, fp16 operands>
+        const void* fn = f16_tile ? (ksel <= 16 ? reinterpret_cast<const void*>(k_knn_f32_reg<16, true>)
+                                                : reinterpret_cast<const void*>(k_knn_f32_reg<32, true>))
+                                  : (ksel <= 16 ? reinterpret_cast<const void*>(k_knn_f32_reg<16, false>)
+                                                : reinterpret_cast<const void*>(k_knn_f32_reg<32, false>));
+        RADAD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_reg_lds_bytes()));
         h->prof.begin(st);
-        hipLaunchKernelGGL(k_knn_f32_reg<16>, grid, dim3(KNN_THREADS), knn_reg_lds_bytes(), st, p);
-        h->prof.end(st);
-    } else if (ksel <= 32 && h->dim % KT_K == 0) {
-        RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32_reg<32>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_reg_lds_bytes()));
-        h->prof.begin(st);
-        hipLaunchKernelGGL(k_knn_f32_reg<32>, grid, dim3(KNN_THREADS), knn_reg_lds_bytes(), st, p);
+        if (f16_tile && ksel <= 16) hipLaunchKernelGGL((k_knn_f32_reg<16, true>), grid, dim3(KNN_THREADS), knn_reg_lds_bytes(), st, p);
+        else if (f16_tile) hipLaunchKernelGGL((k_knn_f32_reg<32, true>), grid, dim3(KNN_THREADS), knn_reg_lds_bytes(), st, p);
+        else if (ksel <= 16) hipLaunchKernelGGL((k_knn_f32_reg<16, false>), grid, dim3(KNN_THREADS), knn_reg_lds_bytes(), st, p);
+        else hipLaunchKernelGGL((k_knn_f32_reg<32, false>), grid, dim3(KNN_THREADS), knn_reg_lds_bytes(), st, p);
         h->prof.end(st);
     } else {
-        RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes()));
+        // generic kernel (any k, any dim % 4 == 0): register staging, lists in the partial arrays; an fp16 store is
+        // decoded to fp32 while staging and multiplied with the fp32 queries
+        const void* fn = h->f16 ? reinterpret_cast<const void*>(k_knn_f32<true>) : reinterpret_cast<const void*>(k_knn_f32<false>);
+        RADAD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_lds_bytes()));
         h->prof.begin(st);
-        hipLaunchKernelGGL(k_knn_f32, grid, dim3(KNN_THREADS), knn_lds_bytes(), st, p);
+        if (h->f16) hipLaunchKernelGGL(k_knn_f32<true>, grid, dim3(KNN_THREADS), knn_lds_bytes(), st, p);
+        else hipLaunchKernelGGL(k_knn_f32<false>, grid, dim3(KNN_THREADS), knn_lds_bytes(), st, p);
         h->prof.end(st);
     }
     RADAD_HIP_CHECK(hipGetLastError());
 
     RefineParams m;
     m.score = ps; m.idx = pi; m.n_parts = n_splits; m.ksel = ksel; m.k = k; m.dim = h->dim; m.l2 = p.l2; m.nq = nq;
-    m.db = h->rows; m.q = q_use; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
+    m.db = h->rows; m.db_f16 = h->f16; m.q = q_use; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
     m.out_key = out_key_dev;
     const size_t per_wave = (((size_t)ksel * 12 + (size_t)n_splits * 4 + 15) & ~(size_t)15) + 16;
     m.waves_per_block = (int)std::max<size_t>(1, std::min<size_t>(4, (60 * 1024) / per_wave));
@@ -1328,8 +1417,12 @@ int radad_knn_reconstruct(radad_knn_t h, const int64_t* idx_dev, int64_t n, floa
     RADAD_REQUIRE(idx_dev && out_dev && n > 0, "radad_knn_reconstruct: bad argument");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
-    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, (hipStream_t)stream, h->rows, idx_dev,
-                       n, h->ntotal, h->id_base, h->dim, out_dev);
+    if (h->f16)
+        hipLaunchKernelGGL(k_gather_rows<_Float16>, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const _Float16*)h->rows, idx_dev, n, h->ntotal, h->id_base, h->dim, out_dev);
+    else
+        hipLaunchKernelGGL(k_gather_rows<float>, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)h->rows, idx_dev, n, h->ntotal, h->id_base, h->dim, out_dev);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
 }
@@ -1345,7 +1438,13 @@ int radad_knn_reconstruct_host(radad_knn_t h, const int64_t* idx_host, int64_t n
         const int64_t r = idx_host[i] - h->id_base;
         float* dst = out_host + i * h->dim;
         if (idx_host[i] < 0 || r < 0 || r >= h->ntotal) { memset(dst, 0, sizeof(float) * h->dim); continue; }
-        RADAD_HIP_CHECK(hipMemcpy(dst, h->rows + r * h->dim, sizeof(float) * h->dim, hipMemcpyDeviceToHost));
+        if (h->f16) {
+            std::vector<_Float16> tmp((size_t)h->dim);
+            RADAD_HIP_CHECK(hipMemcpy(tmp.data(), h->rows + (size_t)r * h->row_bytes(), h->row_bytes(), hipMemcpyDeviceToHost));
+            for (int c = 0; c < h->dim; ++c) dst[c] = (float)tmp[c];
+        } else {
+            RADAD_HIP_CHECK(hipMemcpy(dst, h->rows + (size_t)r * h->row_bytes(), h->row_bytes(), hipMemcpyDeviceToHost));
+        }
     }
     return RADAD_OK;
 }
@@ -1376,7 +1475,8 @@ int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, i
     return RADAD_OK;
 }
 
-// ---- snapshot: "RADADKNN" | u32 version | i32 dim | i32 metric | i64 ntotal | rows fp32 (already normalised for cosine)
+// ---- snapshot: "RADADKNN" | u32 version (2) | i32 dim | i32 metric | i32 store dtype | i64 ntotal | rows as stored
+// (already normalised for cosine; fp32 or fp16).  Version 1 files (no dtype field, fp32 rows) are still read.
 int radad_knn_save(radad_knn_t h, const char* path) {
     RADAD_REQUIRE(h && path, "radad_knn_save: NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1384,17 +1484,18 @@ int radad_knn_save(radad_knn_t h, const char* path) {
     FILE* f = fopen(path, "wb");
     if (!f) { radad_set_error("cannot open %s for writing", path); return RADAD_EIO; }
     const char magic[8] = {'R', 'A', 'D', 'A', 'D', 'K', 'N', 'N'};
-    const uint32_t ver = 1;
-    const int32_t dim = h->dim, metric = h->metric;
+    const uint32_t ver = 2;
+    const int32_t dim = h->dim, metric = h->metric, dtype = h->f16 ? RADAD_STORE_F16 : RADAD_STORE_F32;
     const int64_t nt = h->ntotal;
     bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(&ver, 4, 1, f) == 1 && fwrite(&dim, 4, 1, f) == 1 &&
-              fwrite(&metric, 4, 1, f) == 1 && fwrite(&nt, 8, 1, f) == 1;
-    const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / ((int64_t)h->dim * 4));
-    std::vector<float> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(nt, 1)) * h->dim);
+              fwrite(&metric, 4, 1, f) == 1 && fwrite(&dtype, 4, 1, f) == 1 && fwrite(&nt, 8, 1, f) == 1;
+    const size_t rb = h->row_bytes();
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)((64ull << 20) / rb));
+    std::vector<char> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(nt, 1)) * rb);
     for (int64_t r = 0; ok && r < nt; r += chunk) {
         const int64_t m = std::min<int64_t>(chunk, nt - r);
-        if (hipMemcpy(buf.data(), h->rows + r * h->dim, (size_t)m * h->dim * 4, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
-        ok = fwrite(buf.data(), 4, (size_t)m * h->dim, f) == (size_t)m * h->dim;
+        if (hipMemcpy(buf.data(), h->rows + (size_t)r * rb, (size_t)m * rb, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = fwrite(buf.data(), 1, (size_t)m * rb, f) == (size_t)m * rb;
     }
     ok = (fclose(f) == 0) && ok;
     if (!ok) { radad_set_error("write to %s failed", path); return RADAD_EIO; }
@@ -1405,13 +1506,15 @@ int radad_knn_load(radad_knn_t h, const char* path) {
     RADAD_REQUIRE(h && path, "radad_knn_load: NULL argument");
     FILE* f = fopen(path, "rb");
     if (!f) { radad_set_error("cannot open %s", path); return RADAD_EIO; }
-    char magic[8]; uint32_t ver = 0; int32_t dim = 0, metric = 0; int64_t nt = 0;
-    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "RADADKNN", 8) == 0 && fread(&ver, 4, 1, f) == 1 && ver == 1 &&
-              fread(&dim, 4, 1, f) == 1 && fread(&metric, 4, 1, f) == 1 && fread(&nt, 8, 1, f) == 1;
-    if (!ok || dim != h->dim || metric != h->metric || nt < 0) {
+    char magic[8]; uint32_t ver = 0; int32_t dim = 0, metric = 0, dtype = RADAD_STORE_F32; int64_t nt = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "RADADKNN", 8) == 0 && fread(&ver, 4, 1, f) == 1 && (ver == 1 || ver == 2) &&
+              fread(&dim, 4, 1, f) == 1 && fread(&metric, 4, 1, f) == 1 && (ver == 1 || fread(&dtype, 4, 1, f) == 1) &&
+              fread(&nt, 8, 1, f) == 1;
+    const int32_t want = h->f16 ? RADAD_STORE_F16 : RADAD_STORE_F32;
+    if (!ok || dim != h->dim || metric != h->metric || dtype != want || nt < 0) {
         fclose(f);
-        radad_set_error("%s: bad header or dim/metric mismatch (file dim %d metric %d, handle dim %d metric %d)", path, dim,
-                        metric, h->dim, h->metric);
+        radad_set_error("%s: bad header or mismatch (file dim %d metric %d dtype %d, handle dim %d metric %d dtype %d)", path, dim,
+                        metric, dtype, h->dim, h->metric, want);
         return RADAD_EIO;
     }
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1420,19 +1523,20 @@ int radad_knn_load(radad_knn_t h, const char* path) {
     h->ntotal = 0;
     int rc = knn_grow(h, nt);
     if (rc) { fclose(f); return rc; }
-    const int64_t chunk = std::max<int64_t>(1, (64ll << 20) / ((int64_t)h->dim * 4));
-    std::vector<float> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(nt, 1)) * h->dim);
+    const size_t rb = h->row_bytes();
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)((64ull << 20) / rb));
+    std::vector<char> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(nt, 1)) * rb);
     for (int64_t r = 0; r < nt; r += chunk) {
         const int64_t m = std::min<int64_t>(chunk, nt - r);
-        if (fread(buf.data(), 4, (size_t)m * h->dim, f) != (size_t)m * h->dim) { fclose(f); radad_set_error("%s: truncated", path); return RADAD_EIO; }
-        hipError_t e = hipMemcpy(h->rows + r * h->dim, buf.data(), (size_t)m * h->dim * 4, hipMemcpyHostToDevice);
+        if (fread(buf.data(), 1, (size_t)m * rb, f) != (size_t)m * rb) { fclose(f); radad_set_error("%s: truncated", path); return RADAD_EIO; }
+        hipError_t e = hipMemcpy(h->rows + (size_t)r * rb, buf.data(), (size_t)m * rb, hipMemcpyHostToDevice);
         if (e != hipSuccess) { fclose(f); radad_set_error("H2D copy failed: %s", hipGetErrorString(e)); return RADAD_EHIP; }
     }
     fclose(f);
-    if (h->metric == RADAD_METRIC_L2 && nt > 0) {
-        // rows are stored as added: recompute |y|^2 (mode 1, in place)
-        hipLaunchKernelGGL(k_rows_prepare, dim3((unsigned)ceil_div64(nt, 4)), dim3(256), 0, nullptr, h->rows, h->rows, h->ynorm,
-                           nt, h->dim, 1);
+    if (h->metric == RADAD_METRIC_L2 && nt > 0) {      // |y|^2 is not part of the snapshot
+        const unsigned grid = (unsigned)ceil_div64(nt, 4);
+        if (h->f16) hipLaunchKernelGGL(k_row_sqnorm<_Float16>, dim3(grid), dim3(256), 0, nullptr, (const _Float16*)h->rows, nt, h->dim, h->ynorm);
+        else hipLaunchKernelGGL(k_row_sqnorm<float>, dim3(grid), dim3(256), 0, nullptr, (const float*)h->rows, nt, h->dim, h->ynorm);
         RADAD_HIP_CHECK(hipGetLastError());
         RADAD_HIP_CHECK(hipDeviceSynchronize());
     }
@@ -1470,7 +1574,7 @@ int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int d
     if (n == 0) return RADAD_OK;
     RADAD_REQUIRE(in_dev && out_dev, "radad_rownorm: NULL buffer");
     DeviceGuard g(device);
-    hipLaunchKernelGGL(k_rows_prepare, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, (hipStream_t)stream, in_dev, out_dev,
+    hipLaunchKernelGGL(k_rows_prepare<float>, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, (hipStream_t)stream, in_dev, out_dev,
                        (float*)nullptr, n, dim, 2);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;

@@ -36,14 +36,16 @@ class HipFlatIndex:
 
     is_trained = True   # flat indexes need no training (vector_database.py:124)
 
-    def __init__(self, d: int, metric: int, device: int = 0, id_base: int = 0):
+    def __init__(self, d: int, metric: int, device: int = 0, id_base: int = 0, store_f16: bool = False):
         self._lib = _lib.load()
         self.d = int(d)
         self.metric = int(metric)
         self.device = int(device)
         self.id_base = int(id_base)
+        self.store_f16 = bool(store_f16)      # config.use_float16 (vector_database.py:80): rows kept as IEEE fp16
         h = C.c_void_p()
-        _lib.check(self._lib.radad_knn_create(self.d, self.metric, self.device, self.id_base, C.byref(h)), "radad_knn_create")
+        _lib.check(self._lib.radad_knn_create_ex(self.d, self.metric, _lib.STORE_F16 if self.store_f16 else _lib.STORE_F32,
+                                                 self.device, self.id_base, C.byref(h)), "radad_knn_create")
         self._h = h
 
     def __del__(self):
@@ -181,7 +183,8 @@ class VectorDatabase:
             raise NotImplementedError("IVF (vector_database.py:65-70) is not built; use 'L2' or 'IP' (brute force)")
         else:
             raise ValueError(f"Unsupported index type: {index_type}")
-        self.index = HipFlatIndex(dimension, metric, self.device_id, id_base)
+        self.index = HipFlatIndex(dimension, metric, self.device_id, id_base,
+                                  store_f16=bool(getattr(self.config, "use_float16", False)))          # vector_database.py:80
         logging.info(f"Created HIP flat index on device {self.device_id} dim={dimension} type={index_type}")
 
     # vector_database.py:108-151

@@ -236,3 +236,63 @@ def test_filter_topk_kernel(gpu, tmp_path):
     assert i.cpu().tolist()[0] == [3, 43, 7, 9]
     d, i = vdb.filter_hits(dists[:, :0], idxs[:, :0], 2, excl)                  # no hits at all -> padding
     assert i.cpu().tolist() == [[-1, -1]] * 3 and bool(torch.isnan(d).all())
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
+@pytest.mark.parametrize("n,nq,dim,k", [(20000, 200, 512, 10),     # fp16 MFMA tile kernel (dim % 64 == 0), 16-entry lists
+                                        (9000, 129, 256, 20),      # 32-entry lists
+                                        (5000, 7, 512, 10),        # small batch on an fp16 store: tile kernel
+                                        (4000, 60, 96, 10),        # dim % 64 != 0: decoded to fp32 while staging
+                                        (4000, 60, 128, 40)])      # k too large for register lists: generic kernel
+def test_fp16_store(gpu, metric, n, nq, dim, k):
+    """config.use_float16 (vector_database.py:80): rows rounded to fp16 on add; ranking = float64 over the DECODED rows
+    with the fp32 queries, so ids must equal the oracle run on exactly those rows"""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    lib = _lib.load()
+    m = {"L2": _lib.METRIC_L2, "IP": _lib.METRIC_IP, "COSINE": _lib.METRIC_COSINE}[metric]
+    db = synth.rows(0, n, dim, 2001)
+    q = synth.rows(0, nq, dim, 2002)
+    for j in range(nq):
+        db[(j * 17 + 3) % n] = q[j] + np.float32(0.2) * synth.rows(j, 1, dim, 2003)[0]
+    idx = HipFlatIndex(dim, m, gpu.index or 0, store_f16=True)
+    idx.add(db[: n // 3])
+    idx.add_device(torch.from_numpy(db[n // 3:]).to(gpu))
+    stored = idx.reconstruct_batch(torch.arange(n, device=gpu)).cpu().numpy()          # decoded fp16 rows
+    ref_rows = O.maybe_normalize(db, True).astype(np.float32) if metric == "COSINE" else db
+    assert np.array_equal(stored, stored.astype(np.float16).astype(np.float32))         # every value is an fp16 number
+    np.testing.assert_allclose(stored, ref_rows, rtol=2 ** -10, atol=1e-7)              # within one fp16 rounding of the input
+    qt = torch.from_numpy(q).to(gpu)
+    if metric == "COSINE":
+        qn = torch.empty_like(qt)
+        _lib.check(lib.radad_rownorm(qt.data_ptr(), qn.data_ptr(), nq, dim, gpu.index or 0, _lib.stream_ptr(gpu)))
+        q_used = qn.cpu().numpy()
+    else:
+        q_used = q
+    D, I = idx.search(q, k)
+    od, oi = O.knn(stored, q_used, k, "L2" if metric == "L2" else "IP")
+    np.testing.assert_array_equal(I, oi)
+    np.testing.assert_allclose(D, od, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(idx.reconstruct(5), stored[5], rtol=0, atol=0)
+
+
+def test_fp16_store_save_load_and_config(gpu, tmp_path):
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    cfg = R.Config()
+    cfg.update(device=gpu, vector_db_path=str(tmp_path / "vdb16"), vector_db_index_type="L2", use_float16=True)
+    vdb = R.VectorDatabase(cfg)
+    db = synth.rows(0, 3000, 64, 2101)
+    vdb.add_vectors(db, [f"f{i}.wav" for i in range(3000)], [0] * 3000, {})
+    assert vdb.index.store_f16
+    q = synth.rows(0, 20, 64, 2102)
+    D, I = vdb.search_batch(q, k=7)
+    vdb.save()
+    v2 = R.VectorDatabase(cfg)
+    v2.load()
+    D2, I2 = v2.search_batch(q, k=7)
+    np.testing.assert_array_equal(I, I2)
+    np.testing.assert_array_equal(D, D2)
+    cfg.use_float16 = False
+    v3 = R.VectorDatabase(cfg)
+    v3.load()                                   # dtype mismatch is logged and leaves the store empty (log-and-degrade)
+    assert v3.index is None or v3.index.ntotal == 0
