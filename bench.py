@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU per step")
     ap.add_argument("--db-rows", type=int, default=DB_ROWS, help="total reference-store rows")
     ap.add_argument("--cpu-sample", type=int, default=192, help="clips in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--workload", choices=["fixed", "ragged"], default="fixed",
+                    help="fixed = 4 s clips (the headline); ragged = BASELINE config 3: release_in_the_wild-shaped variable-length "
+                         "clips (log-normal, mean ~4.3 s, clipped to [0.5, 20] s) cut by the segmenter rule")
     ap.add_argument("--store-dtype", choices=["f32", "f16"], default="f32",
                     help="f16 = the reference's use_float16 knob (fp16 rows, fp16 MFMA scan); NOT the headline configuration")
     args = ap.parse_args()
@@ -92,9 +95,24 @@ def main():
     lo, hi = shard_bounds(n_total, world, rank)
 
     # ---- inputs, resident in HBM before the timed region -------------------------------------------------
-    wave = torch.empty(B * CLIP_SAMPLES, device=dev, dtype=torch.float32)
-    _lib.check(lib.radad_synth_audio(wave.data_ptr(), rank * B, B, CLIP_SAMPLES, AUDIO_SEED, local_rank, _lib.stream_ptr(dev)))
-    offsets = np.arange(B + 1, dtype=np.int64) * CLIP_SAMPLES
+    if args.workload == "fixed":
+        wave = torch.empty(B * CLIP_SAMPLES, device=dev, dtype=torch.float32)
+        _lib.check(lib.radad_synth_audio(wave.data_ptr(), rank * B, B, CLIP_SAMPLES, AUDIO_SEED, local_rank, _lib.stream_ptr(dev)))
+        offsets = np.arange(B + 1, dtype=np.int64) * CLIP_SAMPLES
+        n_segments = 3 * B
+    else:
+        # variable-length clips: every clip is generated at 20 s and cut to its own length (device-side slicing)
+        rng = np.random.default_rng(1235 + rank)
+        lens = np.clip(np.exp(rng.normal(np.log(3.6), 0.6, B)), 0.5, 20.0)          # seconds; mean ~4.3
+        lens = (lens * 16000).astype(np.int64)
+        offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        wave = torch.empty(int(offsets[-1]), device=dev, dtype=torch.float32)
+        full = torch.empty(320000, device=dev, dtype=torch.float32)
+        for b in range(B):
+            _lib.check(lib.radad_synth_audio(full.data_ptr(), rank * B + b, 1, 320000, AUDIO_SEED + 1, local_rank, _lib.stream_ptr(dev)))
+            wave[offsets[b]:offsets[b + 1]] = full[:lens[b]]
+        del full
+        n_segments = int(sum(max(1, (int(n) - 32000) // 16000 + 1) for n in lens))
     emb0 = fe.embed_clips(wave, offsets)                              # also the first warm-up of the embed kernels
     gather = ShardedSearch(None, 0)._all_gather
     all_emb = gather(emb0) if world > 1 else emb0
@@ -176,8 +194,11 @@ def main():
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32" if args.store_dtype == "f32" else "f32 embed; f16 store + f16 MFMA scan (f32 accumulate, f64 re-rank)",
         "data": "synthetic",
-        "config": {"workload": f"{B} clips/GPU x 4 s @16 kHz (3 segments), F=512, levels=[1], cosine top-{TOP_K}, "
-                               f"{n_total} x {DIM} fp32 store row-sharded over {world} GPU(s)",
+        "config": {"workload": (f"{B} clips/GPU x 4 s @16 kHz (3 segments)" if args.workload == "fixed" else
+                                f"{B} variable-length clips/GPU (log-normal, mean {float(np.mean(np.diff(offsets))) / 16000:.2f} s, "
+                                f"{n_segments} segments)") +
+                               f", F=512, levels=[1], cosine top-{TOP_K}, {n_total} x {DIM} {args.store_dtype} store "
+                               f"row-sharded over {world} GPU(s)", "segments_per_gpu": n_segments,
                    "clips_per_gpu": B, "db_rows": n_total, "dim": DIM, "k": TOP_K, "parallelism": f"shard{world}",
                    "planted_neighbours_found": planted_ok},
         "roofline": {"kernel": "k_knn_f32_reg<16,%s>" % ("true" if f16 else "false"), "bound": "mfma", "achieved": round(achieved, 2),
@@ -194,11 +215,11 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         from oracle import radad_oracle as O
         ns = min(args.cpu_sample, B)
-        wav_h = wave[: ns * CLIP_SAMPLES].cpu().numpy().reshape(ns, CLIP_SAMPLES)
+        wav_h = [wave[offsets[b]:offsets[b + 1]].cpu().numpy() for b in range(ns)]
         db_h = rows.cpu().numpy()
         cores = len(os.sched_getaffinity(0))
         t0 = time.perf_counter()
-        emb_ref = O.embed_clips(list(wav_h), fe.segment_length, fe.hop_length, fe.proj_w, fe.proj_b, (1,), "max")
+        emb_ref = O.embed_clips(wav_h, fe.segment_length, fe.hop_length, fe.proj_w, fe.proj_b, (1,), "max")
         t_embed = time.perf_counter() - t0
         od, oi = O.knn(db_h, emb_ref, TOP_K, "COSINE", chunk=65536)
         t_cpu = time.perf_counter() - t0

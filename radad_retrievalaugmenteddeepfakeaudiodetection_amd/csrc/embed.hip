@@ -522,7 +522,8 @@ struct radad_embed_s {
     // plan cache + scratch
     std::vector<int64_t> plan_key;       // the clip_offsets the cached plan was built from
     int64_t plan_nseg = 0;
-    DevBuf seg_start, seg_valid, clip_seg, logmel, seg_max, misc;
+    bool plan_uniform = true;            // every clip of the cached plan has the same number of segments
+    DevBuf seg_start, seg_valid, clip_seg, seg_ident, seg_pool, logmel, seg_max, misc;
     EventRing prof_logmel, prof_pool;
     std::mutex mu;
 };
@@ -567,6 +568,17 @@ static int build_plan(radad_embed_t h, const int64_t* clip_offsets, int64_t n_cl
     if ((rc = upload(h->seg_valid, seg_valid.data(), seg_valid.size() * sizeof(int32_t), st))) return rc;
     if ((rc = upload(h->clip_seg, clip_seg.data(), clip_seg.size() * sizeof(int64_t), st))) return rc;
     RADAD_HIP_CHECK(hipStreamSynchronize(st));
+    // ragged batches are pooled per SEGMENT (balanced grid) and averaged afterwards: that path needs the identity
+    // ranges [s, s+1) as its "clip" table
+    bool uniform = true;
+    for (int64_t b = 1; b < n_clips; ++b) uniform = uniform && (clip_seg[b + 1] - clip_seg[b] == clip_seg[1] - clip_seg[0]);
+    if (!uniform) {
+        std::vector<int64_t> ident(seg_start.size() + 1);
+        for (size_t i = 0; i < ident.size(); ++i) ident[i] = (int64_t)i;
+        if ((rc = upload(h->seg_ident, ident.data(), ident.size() * sizeof(int64_t), st))) return rc;
+        RADAD_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    h->plan_uniform = uniform;
     h->plan_key.assign(clip_offsets, clip_offsets + n_clips + 1);
     h->plan_nseg = (int64_t)seg_start.size();
     return RADAD_OK;
@@ -737,6 +749,7 @@ int radad_embed_destroy(radad_embed_t h) {
         if (h->bias) (void)hipFree(h->bias);
         if (h->levels_dev) (void)hipFree(h->levels_dev);
         h->seg_start.release(); h->seg_valid.release(); h->clip_seg.release(); h->logmel.release(); h->seg_max.release();
+        h->seg_ident.release(); h->seg_pool.release();
         h->misc.release();
         h->prof_logmel.destroy();
         h->prof_pool.destroy();
@@ -762,13 +775,25 @@ int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* c
     if ((rc = launch_logmel(h, wave_dev, h->plan_nseg, nullptr, st))) return rc;
     ProjPoolParams p;
     fill_projpool(h, p);
-    p.out = out_dev;
+    const int out_dim = h->nbins * h->cfg.feat_dim;
+    int64_t n_groups = n_clips;           // workgroups along x: clips, or segments for a ragged batch
+    if (h->plan_uniform) {
+        p.out = out_dev;
+    } else {
+        if ((rc = h->seg_pool.ensure((size_t)h->plan_nseg * out_dim * sizeof(float)))) return rc;
+        p.out = (float*)h->seg_pool.p;
+        p.clip_seg = (const int64_t*)h->seg_ident.p;
+        n_groups = h->plan_nseg;
+    }
     h->prof_pool.begin(st);
     if (h->cfg.feat_dim > 256)
-        hipLaunchKernelGGL((k_proj_pool<false, 16>), dim3((unsigned)n_clips, (unsigned)((h->cfg.feat_dim + 511) / 512)), dim3(1024),
+        hipLaunchKernelGGL((k_proj_pool<false, 16>), dim3((unsigned)n_groups, (unsigned)((h->cfg.feat_dim + 511) / 512)), dim3(1024),
                            projpool_lds_bytes(16), st, p);
     else
-        hipLaunchKernelGGL((k_proj_pool<false, 8>), dim3((unsigned)n_clips, 1), dim3(512), projpool_lds_bytes(8), st, p);
+        hipLaunchKernelGGL((k_proj_pool<false, 8>), dim3((unsigned)n_groups, 1), dim3(512), projpool_lds_bytes(8), st, p);
+    if (!h->plan_uniform)                 // pipeline.py:411: mean over each clip's segment vectors, in segment order
+        hipLaunchKernelGGL(k_group_mean, dim3((unsigned)n_clips, (unsigned)((out_dim + 255) / 256)), dim3(256), 0, st,
+                           (const float*)h->seg_pool.p, (const int64_t*)h->clip_seg.p, out_dim, out_dev);
     h->prof_pool.end(st);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
