@@ -31,6 +31,46 @@ def path_tag(path: str) -> int:
     return int.from_bytes(h, "little") & 0x7FFFFFFFFFFFFFFF
 
 
+# ---- faiss IndexFlat file interchange -------------------------------------------------------------------------------
+# The reference persists its store with faiss.write_index (vector_database.py:203) -> `faiss_index.bin`.  faiss is not
+# available here, so this reader/writer follows the published on-disk layout of a flat index from upstream faiss
+# (impl/index_write.cpp: fourcc 'IxF2' (L2) / 'IxFI' (IP), then the index header d:int32, ntotal:int64, two int64
+# dummies, is_trained:uint8, metric_type:int32 [+ metric_arg:float32 if metric_type > 1], then the row data as a
+# uint64 count of 4-byte words followed by ntotal*d float32).  UNVERIFIED against a real faiss build (none in this
+# image): round-trips through this module only; treat as best effort for migrating an existing RADAD deployment.
+def read_faiss_flat(path: str):
+    """-> (metric 'L2'|'IP', d, rows float32 [ntotal, d]); raises ValueError if the file is not a flat faiss index."""
+    with open(path, "rb") as f:
+        fourcc = f.read(4)
+        if fourcc not in (b"IxF2", b"IxFI"):
+            raise ValueError(f"{path}: not a faiss IndexFlat file (fourcc {fourcc!r})")
+        d = int(np.frombuffer(f.read(4), "<i4")[0])
+        ntotal = int(np.frombuffer(f.read(8), "<i8")[0])
+        f.read(16)                                   # two int64 dummies
+        f.read(1)                                    # is_trained
+        metric_type = int(np.frombuffer(f.read(4), "<i4")[0])
+        if metric_type > 1:
+            f.read(4)                                # metric_arg
+        nwords = int(np.frombuffer(f.read(8), "<u8")[0])
+        if d <= 0 or ntotal < 0 or nwords != ntotal * d:
+            raise ValueError(f"{path}: inconsistent faiss header (d={d}, ntotal={ntotal}, words={nwords})")
+        rows = np.fromfile(f, "<f4", nwords).reshape(ntotal, d)
+    return ("L2" if fourcc == b"IxF2" else "IP"), d, rows
+
+
+def write_faiss_flat(path: str, rows: np.ndarray, metric: str):
+    rows = np.ascontiguousarray(rows, "<f4")
+    n, d = rows.shape
+    with open(path, "wb") as f:
+        f.write(b"IxF2" if metric.upper() == "L2" else b"IxFI")
+        f.write(np.int32(d).tobytes()); f.write(np.int64(n).tobytes())
+        f.write(np.int64(1 << 20).tobytes() * 2)
+        f.write(b"\x01")
+        f.write(np.int32(1 if metric.upper() == "L2" else 0).tobytes())     # faiss MetricType: 0 = IP, 1 = L2
+        f.write(np.uint64(n * d).tobytes())
+        rows.tofile(f)
+
+
 class HipFlatIndex:
     """Flat (exhaustive) index living in HBM.  Mirrors the slice of faiss.IndexFlat{L2,IP} the reference uses."""
 
@@ -311,8 +351,19 @@ class VectorDatabase:
             with open(self.metadata_path, "rb") as f:
                 meta = pickle.load(f)
             self.vector_paths, self.vector_labels, self.vector_metadata = meta["paths"], meta["labels"], meta["metadata"]
-            self.create_index(int(meta["dimension"]))
-            self.index.load(self.db_path)
+            with open(self.db_path, "rb") as f:
+                magic = f.read(8)
+            if magic[:4] in (b"IxF2", b"IxFI"):
+                # a store written by the reference itself (faiss.write_index).  For cosine the reference had normalised
+                # the rows before adding them (vector_database.py:118); adding them again re-normalises unit rows, which
+                # changes them by at most one ulp.
+                _, d, rows = read_faiss_flat(self.db_path)
+                self.create_index(d)
+                for s0 in range(0, len(rows), 1 << 18):
+                    self.index.add(rows[s0:s0 + (1 << 18)])
+            else:
+                self.create_index(int(meta["dimension"]))
+                self.index.load(self.db_path)
             logging.info(f"Loaded index; ntotal={self.index.ntotal}")
         except Exception as e:
             logging.error(f"Error loading vector database: {e}")

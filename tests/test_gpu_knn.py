@@ -296,3 +296,30 @@ def test_fp16_store_save_load_and_config(gpu, tmp_path):
     v3 = R.VectorDatabase(cfg)
     v3.load()                                   # dtype mismatch is logged and leaves the store empty (log-and-degrade)
     assert v3.index is None or v3.index.ntotal == 0
+
+
+def test_load_store_written_in_faiss_flat_layout(gpu, tmp_path):
+    """VectorDatabase.load() also accepts `faiss_index.bin` in faiss' IndexFlat on-disk layout (the file the reference
+    writes, vector_database.py:203).  faiss is absent here, so this only round-trips our own writer of that layout."""
+    import pickle
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.vector_database import read_faiss_flat, write_faiss_flat
+    cfg = R.Config()
+    cfg.update(device=gpu, vector_db_path=str(tmp_path / "ref_vdb"), vector_db_index_type="L2")
+    db = synth.rows(0, 2000, 64, 3001)
+    os.makedirs(cfg.vector_db_path, exist_ok=True)
+    write_faiss_flat(os.path.join(cfg.vector_db_path, "faiss_index.bin"), db, "L2")
+    m, d, rows = read_faiss_flat(os.path.join(cfg.vector_db_path, "faiss_index.bin"))
+    assert (m, d) == ("L2", 64) and np.array_equal(rows, db)
+    paths = [f"p{i}.wav" for i in range(2000)]
+    with open(os.path.join(cfg.vector_db_path, "metadata.pkl"), "wb") as f:       # the reference's metadata (vector_database.py:205-213)
+        pickle.dump({"paths": paths, "labels": [0] * 2000, "metadata": {}, "index_type": "L2", "dimension": 64}, f)
+    vdb = R.VectorDatabase(cfg)
+    vdb.load()
+    assert vdb.index.ntotal == 2000 and vdb.vector_paths == paths
+    q = synth.rows(0, 11, 64, 3002)
+    D, I = vdb.search_batch(q, k=6)
+    od, oi = O.knn(db, q, 6, "L2")
+    np.testing.assert_array_equal(I, oi)
+    with pytest.raises(ValueError):
+        read_faiss_flat(os.path.join(cfg.vector_db_path, "metadata.pkl"))
