@@ -99,59 +99,60 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
     const float* src = p.wave + p.seg_start[s];
     const int valid = p.seg_valid[s];
 
-    // ---- stage the segment: raw -> stats -> normalise in place -> reflect borders ---------------------
-    // 16-byte loads, all of a thread's loads in flight before the first LDS write (the HBM latency is paid once)
-    float lsum = 0.f;
-    if ((p.debug & 2) == 0) {
-        const int nv = L >> 2;                                  // L % 160 == 0
+    // ---- stage the segment: HBM -> registers -> (stats, normalise in registers) -> LDS, then reflect borders ----------
+    // A thread holds its 18 x 4 samples in registers for the whole prologue: 16-byte loads all in flight at once (the HBM
+    // latency is paid once), mean and variance (two-pass, as numpy does) reduced straight from the registers, and the
+    // normalised values written to LDS exactly once -- no LDS read-modify-write passes.
+    constexpr int UNR = (MAX_SEG_LEN / 4 + LM_THREADS - 1) / LM_THREADS;      // 18
+    const int nv = L >> 2;                                                  // L % 160 == 0
+    f32x4 raw[UNR];
+    {
         const bool vec_ok = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
-        constexpr int UNR = 6;
-        for (int b0 = 0; b0 < nv; b0 += LM_THREADS * UNR) {
-            f32x4 v[UNR];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int i4 = b0 + u * LM_THREADS + tid;
-                const int i = i4 * 4;
-                f32x4 t = {0.f, 0.f, 0.f, 0.f};
-                if (i4 < nv) {
-                    if (vec_ok && i + 4 <= valid) t = *reinterpret_cast<const f32x4*>(src + i);
-                    else {
+        for (int u = 0; u < UNR; ++u) {
+            const int i4 = u * LM_THREADS + tid;
+            const int i = i4 * 4;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (i4 < nv && !(p.debug & 2)) {
+                if (vec_ok && i + 4 <= valid) t = *reinterpret_cast<const f32x4*>(src + i);
+                else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = i + e < valid ? src[i + e] : 0.f;
-                    }
-                }
-                v[u] = t;
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int i4 = b0 + u * LM_THREADS + tid;
-                if (i4 < nv) {
-                    float* d = sig + sig_pos(i4 * 4 + 200);     // 4 | 200 and 4 | 160: the four samples share one 160-block
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { d[e] = v[u][e]; lsum += v[u][e]; }
+                    for (int e = 0; e < 4; ++e) t[e] = i + e < valid ? src[i + e] : 0.f;
                 }
             }
+            raw[u] = t;
         }
     }
-    float mean = 0.f, sd = 1.f;
+    float mean = 0.f, inv = 1.f;
     if (p.normalize) {
+        float lsum = 0.f;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) lsum += (raw[u][0] + raw[u][1]) + (raw[u][2] + raw[u][3]);   // lanes past nv hold zeros
         mean = block_sum(lsum, scratch, LM_WAVES) / (float)L;
         float lsq = 0.f;
-        for (int i = tid; i < L; i += LM_THREADS) {
-            const float d = sig[sig_pos(i + 200)] - mean;
-            lsq += d * d;
-        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (u * LM_THREADS + tid < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = raw[u][e] - mean; lsq += d * d; }
+            }
         const float var = block_sum(lsq, scratch, LM_WAVES) / (float)L;
-        sd = sqrtf(var + 1e-7f);
-        const float inv = 1.0f / sd;
-        for (int i = tid; i < L; i += LM_THREADS) {
-            const int ps = sig_pos(i + 200);
-            const float v = (sig[ps] - mean) * inv;
-            sig[ps] = v;
-            if (p.norm_out) p.norm_out[(int64_t)s * L + i] = v;
+        inv = 1.0f / sqrtf(var + 1e-7f);
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+        const int i4 = u * LM_THREADS + tid;
+        if (i4 < nv) {
+            f32x4 v = raw[u];
+            if (p.normalize) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * inv;
+            }
+            float* d = sig + sig_pos(i4 * 4 + 200);     // 4 | 200 and 4 | 160: the four samples share one 160-block
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = v[e];
+            if (p.norm_out) *reinterpret_cast<f32x4*>(p.norm_out + (int64_t)s * L + i4 * 4) = v;
         }
-    } else if (p.norm_out) {
-        for (int i = tid; i < L; i += LM_THREADS) p.norm_out[(int64_t)s * L + i] = i < valid ? src[i] : 0.f;
     }
     __syncthreads();
     const int CL = FFT_HOP * (p.nf - 1) + N_FFT + 1;   // chunk samples touched: c in [0, CL)
