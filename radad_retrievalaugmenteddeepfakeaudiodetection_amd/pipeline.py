@@ -60,6 +60,35 @@ class HotPathPipeline:
         flat = torch.from_numpy(np.concatenate(waves) if waves else np.zeros(0, np.float32)).to(self.device)
         return self.embed_waves(flat, offs)                          # [batch, tpp_output_dim]
 
+    # ---- build the store ------------------------------------------------------------------------------------
+    def build_vector_database(self, batches, audio_dataset, save: bool = True):
+        """pipeline.py:416-447 without the host round trip: every batch is embedded on the GPU and appended to the
+        HBM-resident store as a device tensor (the reference does .cpu().numpy() -> np.vstack -> index.add).
+        `batches` yields dicts like the reference's DataLoader does: {'path': [...], 'label': [...], 'metadata': ...}."""
+        self.training_file_ids.clear()
+        n = 0
+        for batch in batches:
+            paths = list(batch["path"])
+            vecs = self.process_audio_batch(paths, audio_dataset)            # [b, D] on the device
+            labels = [int(l) if not hasattr(l, "item") else int(l.item()) for l in batch["label"]]
+            speakers = self._extract_batch_speakers(batch.get("metadata"), len(paths))
+            self.training_file_ids.update(os.path.basename(p) for p in paths)     # pipeline.py:437-438
+            self.vector_db.add_vectors(vecs, paths, labels, {"speaker_id": speakers})
+            n += len(paths)
+        if save:
+            self.vector_db.save()                                             # pipeline.py:446
+        return n
+
+    @staticmethod
+    def _extract_batch_speakers(metas, batch_size):
+        """the speaker_id column the reference keeps beside each vector (pipeline.py:433-443)"""
+        if isinstance(metas, dict) and "speaker_id" in metas:
+            sp = list(metas["speaker_id"])
+            return (sp + ["unknown"] * batch_size)[:batch_size]
+        if isinstance(metas, (list, tuple)) and len(metas) == batch_size:
+            return [m.get("speaker_id", "unknown") if isinstance(m, dict) else "unknown" for m in metas]
+        return ["unknown"] * batch_size
+
     # ---- retrieve -----------------------------------------------------------------------------------------
     def retrieve_similar_vectors(self, query_vectors, query_paths: Optional[List[str]] = None, exclude_self: bool = True,
                                  return_info: bool = False, return_distances: bool = False):
