@@ -136,6 +136,31 @@ int radad_filter_topk(const float* in_dist_dev, const int64_t* in_idx_dev, int64
                       const int64_t* row_tags_dev, int64_t ntotal, int64_t id_base, const int64_t* excl_sorted_dev,
                       int64_t n_excl, float* out_dist_dev, int64_t* out_idx_dev, int device, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Inverted-file flat index: faiss.IndexIVFFlat(IndexFlatL2 quantiser, d, nlist, METRIC_L2), the reference's optional
+ * `vector_db_index_type == "IVF"` (vector_database.py:65-70 create with nlist = max(64, ivf_nlist), :124-128 train on the
+ * first <= 50 000 rows, :174-179 nprobe = config.vector_db_nprobe).  dim must be a multiple of 32, k <= 26.
+ * A search returns the exact top-k (squared L2, ties to the lower id) among the rows of the nprobe lists whose
+ * centroids are nearest to the query; -1 / +inf where those lists hold fewer than k rows.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct radad_ivf_s* radad_ivf_t;
+int radad_ivf_create(int dim, int nlist, int device, radad_ivf_t* out);
+int radad_ivf_destroy(radad_ivf_t h);
+int radad_ivf_is_trained(radad_ivf_t h, int* trained);
+int radad_ivf_ntotal(radad_ivf_t h, int64_t* n);
+int radad_ivf_nlist(radad_ivf_t h, int* nlist);
+/* k-means (Lloyd, `niter` iterations; faiss trains its IVF quantiser with 10) on n training rows; synchronous */
+int radad_ivf_train(radad_ivf_t h, const float* rows_dev, int64_t n, int niter, void* stream);
+/* install centroids computed elsewhere ([nlist, dim] fp32) instead of training; only on an empty index */
+int radad_ivf_set_centroids(radad_ivf_t h, const float* centroids_dev, void* stream);
+int radad_ivf_centroids(radad_ivf_t h, float* out_dev, void* stream);
+/* list of every stored row, in insertion order (host int32 [ntotal]) */
+int radad_ivf_assignments_host(radad_ivf_t h, int32_t* out_host, int64_t cap);
+int radad_ivf_add(radad_ivf_t h, const float* rows_dev, int64_t n, void* stream);               /* synchronous */
+int radad_ivf_search(radad_ivf_t h, const float* q_dev, int64_t nq, int k, int nprobe, float* out_dist_dev,
+                     int64_t* out_idx_dev, void* stream);                                         /* synchronous */
+int radad_ivf_reconstruct(radad_ivf_t h, const int64_t* idx_dev, int64_t n, float* out_dev, void* stream);
+
 /* row L2 normalisation x / (|x| + 1e-12)  (vector_database.py:100-105); in-place allowed */
 int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int device, void* stream);
 

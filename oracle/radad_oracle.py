@@ -248,6 +248,28 @@ def knn_exact_l2_chunked(db, q, k, chunk=4096):
     return bd, bi
 
 
+def ivf_search(db, assign, centroids, q, k, nprobe):
+    """What faiss.IndexIVFFlat(IndexFlatL2, METRIC_L2).search returns for given centroids and list assignments
+    (vector_database.py:65-70,174-181): the exact top-k by squared L2 among the rows whose list is one of the `nprobe`
+    centroids nearest to the query; fewer candidates than k -> id -1 / +inf.  float64, (distance, id) order.
+    faiss is not in the repository (requirements.txt:7,10): restated from its published behaviour, parity unpinned."""
+    db = np.asarray(db, np.float64)
+    q = np.asarray(q, np.float64)
+    _, probes = knn(centroids, q, min(nprobe, len(centroids)), "L2")
+    D = np.full((len(q), k), np.inf)
+    I = np.full((len(q), k), -1, np.int64)
+    assign = np.asarray(assign)
+    for i in range(len(q)):
+        cand = np.flatnonzero(np.isin(assign, probes[i]))
+        if len(cand) == 0:
+            continue
+        d = ((db[cand] - q[i][None, :]) ** 2).sum(1)
+        order = np.lexsort((cand, d))[:k]
+        D[i, :len(order)] = d[order]
+        I[i, :len(order)] = cand[order]
+    return D, I
+
+
 def rank_gaps(dist_sorted):
     """Minimum gap between consecutive ranks per query (used to prove 'bit-exact indices' is testable)."""
     d = np.asarray(dist_sorted, np.float64)

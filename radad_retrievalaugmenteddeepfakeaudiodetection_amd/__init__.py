@@ -8,12 +8,12 @@ shared library (or without a ROCm device) the operators raise.
 from .config import Config
 from .segmenter import AudioSegmenter
 from .pooling import TemporalPyramidPooling
-from .vector_database import HipFlatIndex, VectorDatabase
+from .vector_database import HipFlatIndex, HipIVFFlatIndex, VectorDatabase
 from .feature_extractor import MelProjectionFeatureExtractor, build_feature_extractor
 from .pipeline import HotPathPipeline
 from .projection import ProjectionLayer
 from .sharded import ShardedSearch, shard_bounds
 
-__all__ = ["Config", "AudioSegmenter", "TemporalPyramidPooling", "HipFlatIndex", "VectorDatabase",
+__all__ = ["Config", "AudioSegmenter", "TemporalPyramidPooling", "HipFlatIndex", "HipIVFFlatIndex", "VectorDatabase",
            "MelProjectionFeatureExtractor", "build_feature_extractor", "HotPathPipeline", "ProjectionLayer",
            "ShardedSearch", "shard_bounds"]

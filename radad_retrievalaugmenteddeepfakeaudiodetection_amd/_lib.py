@@ -66,6 +66,18 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "radad_filter_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64,
                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "radad_ivf_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "radad_ivf_destroy": (C.c_int, [C.c_void_p]),
+    "radad_ivf_is_trained": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "radad_ivf_ntotal": (C.c_int, [C.c_void_p, c_i64p]),
+    "radad_ivf_nlist": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "radad_ivf_train": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "radad_ivf_set_centroids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "radad_ivf_centroids": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "radad_ivf_assignments_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "radad_ivf_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "radad_ivf_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "radad_ivf_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "radad_rownorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "radad_embed_create": (C.c_int, [C.POINTER(EmbedCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(C.c_void_p)]),

@@ -802,6 +802,7 @@ struct RefineParams {
     const void* db;           // stored rows (normalised for cosine); fp16 when db_f16
     int db_f16;
     const float* q;           // the fp32 queries (normalised for cosine)
+    const int64_t* id_map;    // optional: reported id = id_map[row] (IVF: list-sorted position -> insertion id), ties by it
     int64_t id_base;
     float* out_dist;          // [nq, k]
     int64_t* out_idx;         // [nq, k]
@@ -875,16 +876,17 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
     // 3) rank by (distance, id): L2 ascending, IP descending; ids are unique so ranks are a permutation
     for (int c = lane; c < nsel; c += 64) {
         const double kc = c_key[c];
-        const int ic = c_id[c];
+        const int64_t ic = p.id_map ? p.id_map[c_id[c]] : (int64_t)c_id[c];
         int rank = 0;
         for (int j = 0; j < nsel; ++j) {
             const double kj = c_key[j];
-            const bool jb = p.l2 ? (kj < kc || (kj == kc && c_id[j] < ic)) : (kj > kc || (kj == kc && c_id[j] < ic));
+            const int64_t ij = p.id_map ? p.id_map[c_id[j]] : (int64_t)c_id[j];
+            const bool jb = p.l2 ? (kj < kc || (kj == kc && ij < ic)) : (kj > kc || (kj == kc && ij < ic));
             rank += jb ? 1 : 0;
         }
         if (rank < p.k) {
             p.out_dist[q * p.k + rank] = (float)kc;
-            p.out_idx[q * p.k + rank] = (int64_t)ic + p.id_base;
+            p.out_idx[q * p.k + rank] = ic + p.id_base;
             if (p.out_key) p.out_key[q * p.k + rank] = kc;
         }
     }
@@ -1373,7 +1375,7 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
 
     RefineParams m;
     m.score = ps; m.idx = pi; m.n_parts = n_splits; m.ksel = ksel; m.k = k; m.dim = h->dim; m.l2 = p.l2; m.nq = nq;
-    m.db = h->rows; m.db_f16 = h->f16; m.q = q_use; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
+    m.db = h->rows; m.db_f16 = h->f16; m.q = q_use; m.id_map = nullptr; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
     m.out_key = out_key_dev;
     const size_t per_wave = (((size_t)ksel * 12 + (size_t)n_splits * 4 + 15) & ~(size_t)15) + 16;
     m.waves_per_block = (int)std::max<size_t>(1, std::min<size_t>(4, (60 * 1024) / per_wave));
@@ -1581,3 +1583,5 @@ int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int d
 }
 
 }  // extern "C"
+
+#include "ivf.inc"

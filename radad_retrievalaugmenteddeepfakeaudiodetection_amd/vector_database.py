@@ -189,6 +189,116 @@ class HipFlatIndex:
         _lib.check(self._lib.radad_knn_load(self._h, os.fsencode(path)), "radad_knn_load")
 
 
+class HipIVFFlatIndex:
+    """faiss.IndexIVFFlat(IndexFlatL2(d), d, nlist, METRIC_L2) on the GPU: the slice of its surface the reference uses
+    (vector_database.py:65-70,124-128,138,174-181; pipeline.py:503): d, nlist, nprobe, is_trained, ntotal, train, add,
+    search, reconstruct."""
+
+    def __init__(self, d: int, nlist: int, device: int = 0, niter: int = 10):
+        self._lib = _lib.load()
+        self.d, self.nlist, self.device, self.niter = int(d), int(nlist), int(device), int(niter)
+        self.nprobe = 1                      # faiss default; the reference sets it from config.vector_db_nprobe (:177)
+        self.id_base = 0
+        self.metric = _lib.METRIC_L2
+        self.store_f16 = False
+        h = C.c_void_p()
+        _lib.check(self._lib.radad_ivf_create(self.d, self.nlist, self.device, C.byref(h)), "radad_ivf_create")
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._lib.radad_ivf_destroy(h)
+            except Exception:
+                pass
+
+    def _dev(self):
+        import torch
+        return torch.device("cuda", self.device)
+
+    @property
+    def is_trained(self) -> bool:
+        t = C.c_int()
+        _lib.check(self._lib.radad_ivf_is_trained(self._h, C.byref(t)))
+        return bool(t.value)
+
+    @property
+    def ntotal(self) -> int:
+        n = C.c_int64()
+        _lib.check(self._lib.radad_ivf_ntotal(self._h, C.byref(n)))
+        return n.value
+
+    def _to_dev(self, x):
+        import torch
+        if isinstance(x, torch.Tensor):
+            return _lib.require_cuda(x, "x").contiguous().float()
+        return torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(self._dev())
+
+    def train(self, x):
+        import torch
+        t = self._to_dev(x)
+        with torch.cuda.device(t.device):
+            _lib.check(self._lib.radad_ivf_train(self._h, t.data_ptr(), t.shape[0], self.niter, _lib.stream_ptr(t.device)), "radad_ivf_train")
+
+    def set_centroids(self, c):
+        import torch
+        t = self._to_dev(c)
+        if tuple(t.shape) != (self.nlist, self.d):
+            raise ValueError(f"centroids must be [{self.nlist}, {self.d}]")
+        with torch.cuda.device(t.device):
+            _lib.check(self._lib.radad_ivf_set_centroids(self._h, t.data_ptr(), _lib.stream_ptr(t.device)), "radad_ivf_set_centroids")
+
+    def centroids(self) -> np.ndarray:
+        import torch
+        out = torch.empty((self.nlist, self.d), device=self._dev())
+        with torch.cuda.device(out.device):
+            _lib.check(self._lib.radad_ivf_centroids(self._h, out.data_ptr(), _lib.stream_ptr(out.device)))
+        return out.cpu().numpy()
+
+    def assignments(self) -> np.ndarray:
+        out = np.empty(self.ntotal, np.int32)
+        _lib.check(self._lib.radad_ivf_assignments_host(self._h, out.ctypes.data, out.size))
+        return out
+
+    def add(self, x):
+        import torch
+        t = self._to_dev(x)
+        if t.dim() != 2 or t.shape[1] != self.d:
+            raise ValueError(f"add expects [n, {self.d}], got {tuple(t.shape)}")
+        with torch.cuda.device(t.device):
+            _lib.check(self._lib.radad_ivf_add(self._h, t.data_ptr(), t.shape[0], _lib.stream_ptr(t.device)), "radad_ivf_add")
+
+    add_device = add
+
+    def search_device(self, q, k: int):
+        import torch
+        q = self._to_dev(q)
+        D = torch.empty((q.shape[0], k), device=q.device, dtype=torch.float32)
+        I = torch.empty((q.shape[0], k), device=q.device, dtype=torch.int64)
+        with torch.cuda.device(q.device):
+            _lib.check(self._lib.radad_ivf_search(self._h, q.data_ptr(), q.shape[0], int(k), int(self.nprobe), D.data_ptr(), I.data_ptr(),
+                                                  _lib.stream_ptr(q.device)), "radad_ivf_search")
+        return D, I
+
+    def search(self, x, k: int):
+        D, I = self.search_device(x, k)
+        return D.cpu().numpy(), I.cpu().numpy()
+
+    def reconstruct_batch(self, idx):
+        import torch
+        _lib.require_cuda(idx, "idx")
+        flat = idx.contiguous().to(torch.int64).reshape(-1)
+        out = torch.empty((flat.numel(), self.d), device=idx.device, dtype=torch.float32)
+        with torch.cuda.device(idx.device):
+            _lib.check(self._lib.radad_ivf_reconstruct(self._h, flat.data_ptr(), flat.numel(), out.data_ptr(), _lib.stream_ptr(idx.device)))
+        return out.reshape(*idx.shape, self.d)
+
+    def reconstruct(self, i: int) -> np.ndarray:
+        import torch
+        return self.reconstruct_batch(torch.tensor([int(i)], device=self._dev()))[0].cpu().numpy()
+
+
 class VectorDatabase:
     """Store of clip embeddings + brute-force retrieval (vector_database.py:8-272)."""
 
@@ -220,7 +330,10 @@ class VectorDatabase:
         elif index_type == "IP":
             metric = _lib.METRIC_COSINE if self._cosine else _lib.METRIC_IP
         elif index_type == "IVF":
-            raise NotImplementedError("IVF (vector_database.py:65-70) is not built; use 'L2' or 'IP' (brute force)")
+            nlist = max(64, int(getattr(self.config, "ivf_nlist", 4096)))                     # vector_database.py:67-68
+            self.index = HipIVFFlatIndex(dimension, nlist, self.device_id)
+            logging.info(f"Created HIP IVF-flat index on device {self.device_id} dim={dimension} nlist={nlist}")
+            return
         else:
             raise ValueError(f"Unsupported index type: {index_type}")
         self.index = HipFlatIndex(dimension, metric, self.device_id, id_base,
@@ -237,6 +350,12 @@ class VectorDatabase:
         is_dev = hasattr(vectors, "is_cuda") and vectors.is_cuda
         if not is_dev:
             vectors = np.ascontiguousarray(np.asarray(vectors).astype(np.float32, copy=False))
+        try:     # IVF: train once, on a representative prefix, before adding (vector_database.py:122-130)
+            if hasattr(self.index, "is_trained") and not self.index.is_trained:
+                logging.info("Training IVF index...")
+                self.index.train(vectors[:min(50000, vectors.shape[0])])
+        except Exception as e:
+            logging.warning(f"Index training skipped/failed: {e}")
         total = vectors.shape[0]
         added = 0
         for start in range(0, total, batch_size):
@@ -283,6 +402,11 @@ class VectorDatabase:
                 return (torch.zeros((len(query_vectors), 0), dtype=torch.float32, device=query_vectors.device),
                         torch.zeros((len(query_vectors), 0), dtype=torch.int64, device=query_vectors.device))
             return np.zeros((len(query_vectors), 0), dtype=np.float32), np.zeros((len(query_vectors), 0), dtype=np.int64)
+        try:     # IVF: tune nprobe (vector_database.py:174-179)
+            if hasattr(self.index, "nprobe") and hasattr(self.config, "vector_db_nprobe"):
+                self.index.nprobe = int(self.config.vector_db_nprobe)
+        except Exception:
+            pass
         if is_dev:
             return self.index.search_device(query_vectors, k)
         return self.index.search(query_vectors.astype(np.float32, copy=False), k)
@@ -333,7 +457,16 @@ class VectorDatabase:
             if self.index is None:
                 logging.warning("No index to save.")
                 return
-            self.index.save(self.db_path)
+            if isinstance(self.index, HipIVFFlatIndex):
+                # centroids + rows in insertion order; assignments are recomputed on load (deterministic: nearest centroid)
+                import torch
+                ids = torch.arange(self.index.ntotal, device=torch.device("cuda", self.device_id))
+                rows = np.concatenate([self.index.reconstruct_batch(ids[s0:s0 + (1 << 17)]).cpu().numpy()
+                                       for s0 in range(0, self.index.ntotal, 1 << 17)]) if self.index.ntotal else np.zeros((0, self.index.d), np.float32)
+                with open(self.db_path, "wb") as f:
+                    np.savez(f, kind="radad_ivf", centroids=self.index.centroids(), rows=rows)
+            else:
+                self.index.save(self.db_path)
             meta = {"paths": self.vector_paths, "labels": self.vector_labels, "metadata": self.vector_metadata,
                     "index_type": self.config.vector_db_index_type, "dimension": self.index.d}
             with open(self.metadata_path, "wb") as f:
@@ -353,7 +486,15 @@ class VectorDatabase:
             self.vector_paths, self.vector_labels, self.vector_metadata = meta["paths"], meta["labels"], meta["metadata"]
             with open(self.db_path, "rb") as f:
                 magic = f.read(8)
-            if magic[:4] in (b"IxF2", b"IxFI"):
+            if magic[:2] == b"PK":                      # numpy .npz: an IVF store written by save() above
+                z = np.load(self.db_path)
+                self.create_index(int(z["centroids"].shape[1]))
+                if not isinstance(self.index, HipIVFFlatIndex) or self.index.nlist != z["centroids"].shape[0]:
+                    raise ValueError("saved IVF store does not match config (index type / ivf_nlist)")
+                self.index.set_centroids(z["centroids"])
+                for s0 in range(0, len(z["rows"]), 1 << 18):
+                    self.index.add(z["rows"][s0:s0 + (1 << 18)])
+            elif magic[:4] in (b"IxF2", b"IxFI"):
                 # a store written by the reference itself (faiss.write_index).  For cosine the reference had normalised
                 # the rows before adding them (vector_database.py:118); adding them again re-normalises unit rows, which
                 # changes them by at most one ulp.
