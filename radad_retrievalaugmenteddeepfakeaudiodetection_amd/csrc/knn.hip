@@ -1258,8 +1258,20 @@ int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float
     return radad_knn_search_f64(h, q_dev, nq, k, out_dist_dev, out_idx_dev, nullptr, stream);
 }
 
+static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k, int margin, float* out_dist_dev,
+                           int64_t* out_idx_dev, double* out_key_dev, void* stream);
+
 int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev, int64_t* out_idx_dev,
                          double* out_key_dev, void* stream) {
+    return knn_search_core(h, q_dev, nq, k, KNN_MARGIN, out_dist_dev, out_idx_dev, out_key_dev, stream);
+}
+
+}  // extern "C"
+
+// `margin` spare candidates per query reach the float64 re-rank (KNN_MARGIN for user searches; the IVF coarse quantiser
+// asks for fewer so that nprobe = 32 still fits the 32-entry register lists)
+static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k, int margin, float* out_dist_dev,
+                           int64_t* out_idx_dev, double* out_key_dev, void* stream) {
     RADAD_REQUIRE(h, "NULL handle");
     RADAD_REQUIRE(k >= 1 && k <= RADAD_KNN_MAX_K, "radad_knn_search: k=%d outside [1,%d]", k, RADAD_KNN_MAX_K);
     RADAD_REQUIRE(nq >= 0 && nq < (1ll << 31) - KT_N, "radad_knn_search: bad nq");
@@ -1273,7 +1285,7 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     int64_t chunk_rows;
     knn_geometry(std::max<int64_t>(h->ntotal, 1), nq, &n_qtiles, &n_splits, &chunk_rows);
     // small batches (the online predict case) take the HBM-bound streaming kernel: one list per WAVE
-    const bool smallq = !h->f16 && nq <= SQ_NQ && h->dim % 32 == 0 && h->dim <= SQ_MAX_DIM && k + KNN_MARGIN <= 32 && h->ntotal > 0;
+    const bool smallq = !h->f16 && nq <= SQ_NQ && h->dim % 32 == 0 && h->dim <= SQ_MAX_DIM && k + margin <= 32 && h->ntotal > 0;
     int sq_rows_per_wave = 0;
     if (smallq) {
         const int64_t waves_wanted = 256 * 8;                                     // 8 waves (2 workgroups) per CU
@@ -1289,7 +1301,7 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     // workspace: [qn: nq*dim fp32] (cosine) | [qh: nq*dim fp16] (fp16 store) | part_score | part_idx
     const size_t qn_bytes = h->metric == RADAD_METRIC_COSINE ? (size_t)nq * h->dim * sizeof(float) : 0;
     const size_t qnorm_bytes = h->f16 ? ((((size_t)nq * h->dim * 2) + 255) & ~(size_t)255) : 256;
-    const size_t part_elems = (size_t)nq * n_splits * (k + KNN_MARGIN);
+    const size_t part_elems = (size_t)nq * n_splits * (k + margin);
     const size_t off_qnorm = (qn_bytes + 255) & ~(size_t)255;
     const size_t off_ps = off_qnorm + qnorm_bytes;
     const size_t off_pi = off_ps + ((part_elems * sizeof(float) + 255) & ~(size_t)255);
@@ -1314,7 +1326,7 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     // (|q|^2 is not needed: ranking uses 2 q.y - |y|^2 and the reported distance is re-scored exactly)
     // fp16 store + DMA tile kernel: the scan multiplies fp16 x fp16 (fp32 accumulate), so it gets an fp16 copy of the
     // (normalised) queries; the float64 re-rank below still uses the fp32 queries against the decoded rows.
-    const int ksel = k + KNN_MARGIN;             // the scan keeps a few spare candidates for the float64 re-rank
+    const int ksel = k + margin;                 // the scan keeps a few spare candidates for the float64 re-rank
     const bool f16_tile = h->f16 && ksel <= 32 && h->dim % 64 == 0;
     if (f16_tile)
         hipLaunchKernelGGL(k_rows_prepare<_Float16>, dim3(rgrid), dim3(256), 0, st, q_use, qh, (float*)nullptr, nq, h->dim, 0);
@@ -1384,6 +1396,8 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
 }
+
+extern "C" {
 
 int radad_knn_search_host(radad_knn_t h, const float* q_host, int64_t nq, int k, float* out_dist_host,
                           int64_t* out_idx_host) {
