@@ -236,6 +236,10 @@ int radad_group_mean(const float* in_dev, const int64_t* group_offsets_host, int
  *   s = W2 tanh(W1 x + b1) + b2; a = softmax_K(s); c = W4 relu(W3 x + b3) + b4; u = sum_K a c;
  *   out = W6 LN(W5 u + b5; eps 1e-6) + b6
  * Weights are given in torch nn.Linear layout ([out, in] row-major), device pointers.
+ * One pass over x: a split-K GEMM against [W1;W3], then one block per batch row (csrc/proj.hip).
+ * w54t / b54 hold the inference-time fold  W5 (W4 h + b4) + b5 = (W5 W4) h + (W5 b4 + b5): build them once
+ * per set of weights with radad_projection_fold and keep them; when NULL the forward re-folds into its
+ * workspace on every call (correct, slower).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct radad_proj_weights {
     const float *w1, *b1;       /* attention_score   [H, D], [H]   */
@@ -245,11 +249,46 @@ typedef struct radad_proj_weights {
     const float *w5, *b5;       /* weight_sum        [H, D], [H]   */
     const float *ln_g, *ln_b;   /* normalization     [H], [H]      */
     const float *w6, *b6;       /* unified_embedding [O, H], [O]   */
+    const float *w54t, *b54;    /* optional fold: (W5 W4)^T [H(in), H(out)], W5 b4 + b5 [H]; NULL = fold per call */
 } radad_proj_weights;
 int radad_projection_forward(const radad_proj_weights* w, const float* x_dev /*[B,K,D]*/, int64_t batch, int k,
                              int dim, int hidden, int out_dim, float* out_dev /*[B,O]*/, float* workspace_dev,
                              int64_t workspace_bytes, int device, void* stream);
 int64_t radad_projection_workspace_bytes(int64_t batch, int k, int dim, int hidden, int out_dim);
+/* w54t_out_dev [H,H], b54_out_dev [H] from w->w4,b4,w5,b5 (float64 accumulation, rounded once) */
+int radad_projection_fold(const radad_proj_weights* w, int dim, int hidden, float* w54t_out_dev, float* b54_out_dev,
+                          int device, void* stream);
+
+/* out[r, :] = act(W x[r, :] + bias)   nn.Linear forward, W [out_features, in_features] with row stride ldw;
+ * act 0 none / 1 tanh / 2 relu.  Split-K MFMA GEMM (few rows x wide in_features still fills the chip). */
+int radad_linear_forward(const float* x_dev, int64_t ldx, const float* w_dev, int64_t ldw, const float* bias_dev,
+                         int act, int64_t rows, int out_features, int in_features, float* out_dev, int64_t ldo,
+                         float* workspace_dev, int64_t workspace_bytes, int device, void* stream);
+int64_t radad_linear_workspace_bytes(int64_t rows, int out_features, int in_features);
+
+/* ------------------------------------------------------------------------------------------------
+ * RADADModel.forward after the projection (radad_model.py:38-41), inference:
+ *   fused  = Wf cat[tpp, proj] + bf                      (:39; the concatenation is never built)
+ *   logits = DetectionModel(fused)                       (:40; detection_model.py:41-72 in eval mode:
+ *            per hidden layer Linear -> BatchNorm1d (running stats, given as scale/shift) -> ReLU;
+ *            dropout = identity; last layer Linear only)
+ * n_layers == 0 stops after the fuse Linear.  Either output pointer may be NULL when not wanted.
+ * ---------------------------------------------------------------------------------------------- */
+#define RADAD_HEAD_MAX_LAYERS 6
+typedef struct radad_head_weights {
+    const float *wf, *bf;                           /* fuse [P, D+P], [P]                                  */
+    int32_t n_layers;                               /* Linear layers of the detection MLP                  */
+    int32_t dims[RADAD_HEAD_MAX_LAYERS + 1];        /* dims[0] = P, dims[i+1] = out width of layer i       */
+    const float* lw[RADAD_HEAD_MAX_LAYERS];         /* [dims[i+1], dims[i]]                                */
+    const float* lb[RADAD_HEAD_MAX_LAYERS];         /* [dims[i+1]]                                         */
+    const float* bn_scale[RADAD_HEAD_MAX_LAYERS];   /* gamma / sqrt(running_var + eps), or NULL            */
+    const float* bn_shift[RADAD_HEAD_MAX_LAYERS];   /* beta - running_mean * scale, or NULL                */
+} radad_head_weights;
+int radad_fuse_head_forward(const radad_head_weights* w, const float* tpp_dev /*[B,D]*/, const float* proj_dev /*[B,P]*/,
+                            int64_t batch, int dim, int proj_dim, float* fused_out_dev /*[B,P] or NULL*/,
+                            float* logits_out_dev /*[B, dims[n_layers]]*/, float* workspace_dev,
+                            int64_t workspace_bytes, int device, void* stream);
+int64_t radad_fuse_head_workspace_bytes(int64_t batch, int dim, int proj_dim);
 
 /* ------------------------------------------------------------------------------------------------
  * Synthetic inputs (bench / tests only): a stateless integer hash so host and device produce the

@@ -344,3 +344,26 @@ def projection_forward(x, p):
     var = ((y - mu) ** 2).mean(axis=1, keepdims=True)
     y = (y - mu) / np.sqrt(var + 1e-6) * f(p["normalization.weight"]) + f(p["normalization.bias"])  # :99, eps :51
     return y @ f(p["unified_embedding.weight"]).T + f(p["unified_embedding.bias"])           # :101
+
+
+def radad_model_forward(neighbor_vecs, tpp_vecs, p, bn_eps=1e-5):
+    """RADADModel eval forward (radad_model.py:32-41) with the reference's state_dict names; float64.
+    Returns (proj [B,P], fused [B,P], logits [B])."""
+    f = lambda a: np.asarray(a, np.float64)
+    proj = projection_forward(neighbor_vecs, {k[len("projection_layer."):]: v for k, v in p.items()
+                                              if k.startswith("projection_layer.")})               # :38
+    fused = np.concatenate([f(tpp_vecs), proj], axis=1) @ f(p["fuse.weight"]).T + f(p["fuse.bias"])  # :39
+    # detection_model.py:45-72: nn.Sequential indices in order; Linear, then (BatchNorm1d eval, ReLU) except last
+    idx = sorted({int(k.split(".")[2]) for k in p if k.startswith("detection_model.model.")})
+    lin = [i for i in idx if np.ndim(p[f"detection_model.model.{i}.weight"]) == 2]
+    h = fused
+    for n, i in enumerate(lin):
+        h = h @ f(p[f"detection_model.model.{i}.weight"]).T + f(p[f"detection_model.model.{i}.bias"])
+        if n + 1 < len(lin):
+            b = i + 1
+            if f"detection_model.model.{b}.running_mean" in p:
+                h = (h - f(p[f"detection_model.model.{b}.running_mean"])) / np.sqrt(
+                    f(p[f"detection_model.model.{b}.running_var"]) + bn_eps)
+                h = h * f(p[f"detection_model.model.{b}.weight"]) + f(p[f"detection_model.model.{b}.bias"])
+            h = np.maximum(h, 0.0)
+    return proj, fused, (h[:, 0] if h.shape[1] == 1 else h)                                         # squeeze(-1) :125

@@ -12,8 +12,9 @@ from .vector_database import HipFlatIndex, HipIVFFlatIndex, VectorDatabase
 from .feature_extractor import MelProjectionFeatureExtractor, build_feature_extractor
 from .pipeline import HotPathPipeline
 from .projection import ProjectionLayer
+from .radad_model import DetectionModel, RADADModel
 from .sharded import ShardedSearch, shard_bounds
 
 __all__ = ["Config", "AudioSegmenter", "TemporalPyramidPooling", "HipFlatIndex", "HipIVFFlatIndex", "VectorDatabase",
-           "MelProjectionFeatureExtractor", "build_feature_extractor", "HotPathPipeline", "ProjectionLayer",
+           "MelProjectionFeatureExtractor", "build_feature_extractor", "HotPathPipeline", "ProjectionLayer", "DetectionModel", "RADADModel",
            "ShardedSearch", "shard_bounds"]

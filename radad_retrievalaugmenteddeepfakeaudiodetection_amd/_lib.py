@@ -30,7 +30,17 @@ class EmbedCfg(C.Structure):
 
 class ProjWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1", "b1", "w2", "b2", "w3", "b3", "w4", "b4", "w5", "b5",
-                                          "ln_g", "ln_b", "w6", "b6")]
+                                          "ln_g", "ln_b", "w6", "b6", "w54t", "b54")]
+
+
+HEAD_MAX_LAYERS = 6
+
+
+class HeadWeights(C.Structure):
+    _fields_ = [("wf", C.c_void_p), ("bf", C.c_void_p), ("n_layers", C.c_int32),
+                ("dims", C.c_int32 * (HEAD_MAX_LAYERS + 1)),
+                ("lw", C.c_void_p * HEAD_MAX_LAYERS), ("lb", C.c_void_p * HEAD_MAX_LAYERS),
+                ("bn_scale", C.c_void_p * HEAD_MAX_LAYERS), ("bn_shift", C.c_void_p * HEAD_MAX_LAYERS)]
 
 
 # name -> (restype, argtypes); every symbol include/radad_hip.h declares
@@ -96,6 +106,15 @@ SIGNATURES = {
     "radad_projection_forward": (C.c_int, [C.POINTER(ProjWeights), C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int,
                                            C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "radad_projection_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "radad_projection_fold": (C.c_int, [C.POINTER(ProjWeights), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p]),
+    "radad_linear_forward": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int64,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int,
+                                       C.c_void_p]),
+    "radad_linear_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
+    "radad_fuse_head_forward": (C.c_int, [C.POINTER(HeadWeights), C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    "radad_fuse_head_workspace_bytes": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "radad_synth_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_int, C.c_void_p]),
     "radad_synth_audio": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_uint64, C.c_int, C.c_void_p]),
 }

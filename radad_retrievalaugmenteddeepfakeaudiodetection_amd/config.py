@@ -34,6 +34,11 @@ class Config:
         self.use_mixed_precision = False
         self.use_gradient_checkpointing = False
         self.fuse_attention_ops = True
+        # detection head (config.py:63, 82-86; the later assignment of detection_dropout wins there too)
+        self.detection_hidden_dims = [64, 32]
+        self.detection_dropout = 0.1
+        self.use_batch_norm = True
+        self.use_layer_norm = False
         # device (config.py:89)
         import torch
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")

@@ -37,6 +37,7 @@ class ProjectionLayer(nn.Module):
                 nn.init.zeros_(m.bias)
         self.to(self.device)
         self._ws = None
+        self._fold = None        # (key, w54t [H,H], b54 [H]): W5 (W4 h + b4) + b5 folded once per set of weights
 
     def forward(self, input_embeddings: torch.Tensor) -> torch.Tensor:
         """projection.py:108-117 (eval path).  input [B, top_k, D] -> [B, output_dim]."""
@@ -55,9 +56,19 @@ class ProjectionLayer(nn.Module):
         need = lib.radad_projection_workspace_bytes(B, K, D, self.hidden_dim, self.output_dim)
         if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
             self._ws = torch.empty(int(need), dtype=torch.uint8, device=x.device)
+        w, keep = self._weights(x.device)
+        out = torch.empty((B, self.output_dim), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.radad_projection_forward(C.byref(w), x.data_ptr(), B, K, D, self.hidden_dim, self.output_dim,
+                                                    out.data_ptr(), self._ws.data_ptr(), int(self._ws.numel()),
+                                                    x.device.index, _lib.stream_ptr(x.device)), "radad_projection_forward")
+        return out
+
+    def _weights(self, device):
+        """C struct of device pointers (+ the tensors that must outlive the launch) with the cached W5*W4 fold."""
+        lib = _lib.load()
         w = _lib.ProjWeights()
-        f = lambda t: C.c_void_p(t.detach().contiguous().float().data_ptr())
-        keep = []   # keep contiguous copies alive until the launch is enqueued
+        keep = []   # contiguous fp32 views stay alive until the launch is enqueued
 
         def ptr(t):
             t = t.detach().contiguous().float()
@@ -70,12 +81,19 @@ class ProjectionLayer(nn.Module):
         w.w5, w.b5 = ptr(self.weight_sum.weight), ptr(self.weight_sum.bias)
         w.ln_g, w.ln_b = ptr(self.normalization.weight), ptr(self.normalization.bias)
         w.w6, w.b6 = ptr(self.unified_embedding.weight), ptr(self.unified_embedding.bias)
-        out = torch.empty((B, self.output_dim), device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
-            _lib.check(lib.radad_projection_forward(C.byref(w), x.data_ptr(), B, K, D, self.hidden_dim, self.output_dim,
-                                                    out.data_ptr(), self._ws.data_ptr(), int(self._ws.numel()),
-                                                    x.device.index, _lib.stream_ptr(x.device)), "radad_projection_forward")
-        return out
+        # in-place updates (load_state_dict, optimizer steps) bump _version; a new Parameter changes data_ptr
+        src = (self.cst_output.weight, self.cst_output.bias, self.weight_sum.weight, self.weight_sum.bias)
+        key = tuple((t.data_ptr(), t._version) for t in src) + (str(device),)
+        if self._fold is None or self._fold[0] != key:
+            H = self.hidden_dim
+            w54t = torch.empty((H, H), device=device, dtype=torch.float32)
+            b54 = torch.empty((H,), device=device, dtype=torch.float32)
+            with torch.cuda.device(device):
+                _lib.check(lib.radad_projection_fold(C.byref(w), self.input_dim, H, w54t.data_ptr(), b54.data_ptr(),
+                                                     device.index, _lib.stream_ptr(device)), "radad_projection_fold")
+            self._fold = (key, w54t, b54)
+        w.w54t, w.b54 = self._fold[1].data_ptr(), self._fold[2].data_ptr()
+        return w, keep
 
     def forward_batch(self, input_embeddings_list: list) -> torch.Tensor:
         """projection.py:119-122."""

@@ -45,6 +45,107 @@ def test_projection_matches_reference_golden(gpu, golden_dir, D):
         layer(x)
 
 
+def test_projection_fold_cache_and_unfolded_call(gpu):
+    """The W5*W4 fold is rebuilt when the weights change (load_state_dict / in-place update), and the C entry point
+    gives the same answer when the caller passes no fold (w54t = NULL: folded per call into the workspace)."""
+    import ctypes as C
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+    D = 448
+    cfg = R.Config()
+    cfg.update(device=gpu)
+    layer = R.ProjectionLayer(cfg, D).eval()
+    x = torch.from_numpy(synth.rows(0, 9 * 5, D, 31).reshape(9, 5, D)).to(gpu)
+    for seed in (11, 12):
+        sd = synth.fill_state_dict(_proj_shapes(D), seed)
+        layer.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        with torch.no_grad():
+            y = layer(x).cpu().numpy()
+        np.testing.assert_allclose(y, O.projection_forward(x.cpu().numpy(), sd), rtol=0, atol=1e-4)
+    with torch.no_grad():
+        layer.weight_sum.bias.add_(0.25)            # in-place edit: the cached fold must not survive it
+        sd["weight_sum.bias"] = sd["weight_sum.bias"] + np.float32(0.25)
+        y = layer(x).cpu().numpy()
+    np.testing.assert_allclose(y, O.projection_forward(x.cpu().numpy(), sd), rtol=0, atol=1e-4)
+    lib = _lib.load()
+    w, keep = layer._weights(x.device)
+    w.w54t, w.b54 = None, None
+    need = lib.radad_projection_workspace_bytes(9, 5, D, 256, 128)
+    ws = torch.empty(int(need), dtype=torch.uint8, device=gpu)
+    out = torch.empty((9, 128), device=gpu)
+    _lib.check(lib.radad_projection_forward(C.byref(w), x.data_ptr(), 9, 5, D, 256, 128, out.data_ptr(), ws.data_ptr(),
+                                            int(need), x.device.index, _lib.stream_ptr(x.device)), "forward")
+    np.testing.assert_allclose(out.cpu().numpy(), y, rtol=0, atol=2e-6)
+    with pytest.raises(ValueError, match="workspace too small"):
+        _lib.check(lib.radad_projection_forward(C.byref(w), x.data_ptr(), 9, 5, D, 256, 128, out.data_ptr(), ws.data_ptr(),
+                                                16, x.device.index, _lib.stream_ptr(x.device)), "forward")
+
+
+def test_radad_model_matches_reference_golden(gpu, golden_dir):
+    """radad_model.py:32-41 end to end: projection -> fuse Linear over [tpp ; proj] -> detection MLP (BatchNorm in
+    eval form), against the reference module's own outputs and, at a ragged batch, against the oracle."""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    g = np.load(os.path.join(golden_dir, "projection.npz"))
+    names = [str(n) for n in g["radad_names"]]
+    shapes = {n: tuple(int(v) for v in str(s).split(",") if v) for n, s in zip(names, g["radad_shapes"])}
+    sd = synth.fill_state_dict(shapes, int(g["radad_seed"]))
+    cfg = R.Config()
+    cfg.update(device=gpu)
+    D = 512
+    model = R.RADADModel(cfg, D).eval()
+    assert list(model.state_dict().keys()) == names                                 # the reference's own key names
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x, t = torch.from_numpy(g["radad_x"]).to(gpu), torch.from_numpy(g["radad_t"]).to(gpu)
+    with torch.no_grad():
+        proj = model.projection_layer(x)
+        logits, fused = model.fuse_and_detect(t, proj, return_fused=True)
+        logits2 = model(x, t)
+    np.testing.assert_allclose(proj.cpu().numpy(), g["radad_proj"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(fused.cpu().numpy(), g["radad_fused"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["radad_logits"], rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(logits.cpu().numpy(), logits2.cpu().numpy())
+    assert logits.shape == (3,)
+    B = 301                                                                         # several 128-row tiles + a tail
+    xb = synth.rows(0, B * 5, D, 401).reshape(B, 5, D)
+    tb = synth.rows(0, B, D, 402)
+    with torch.no_grad():
+        lb = model(torch.from_numpy(xb).to(gpu), torch.from_numpy(tb).to(gpu)).cpu().numpy()
+        pb = model.predict_proba(torch.from_numpy(xb).to(gpu), torch.from_numpy(tb).to(gpu)).cpu().numpy()
+    _, _, want = O.radad_model_forward(xb, tb, sd)
+    np.testing.assert_allclose(lb, want, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(pb, 1.0 / (1.0 + np.exp(-want)), rtol=0, atol=1e-4)
+    model.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        model(x, t)
+
+
+@pytest.mark.parametrize("rows,n_out,n_in,act", [(1, 256, 5376, 0), (37, 100, 516, 1), (300, 130, 64, 2), (0, 8, 8, 0)])
+def test_linear_forward_split_k(gpu, rows, n_out, n_in, act):
+    """radad_linear_forward = nn.Linear (+ tanh / relu) for shapes from one row x wide K (many K-splits) to ragged."""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+    lib = _lib.load()
+    x = synth.rows(0, max(rows, 1), n_in, 5)[:rows]
+    w = synth.rows(0, n_out, n_in, 6) / np.float32(np.sqrt(n_in))
+    b = synth.rows(0, 1, n_out, 7)[0]
+    xd, wd, bd = (torch.from_numpy(np.ascontiguousarray(a)).to(gpu) for a in (x, w, b))
+    out = torch.full((rows, n_out), 7.0, device=gpu)
+    need = lib.radad_linear_workspace_bytes(rows, n_out, n_in)
+    ws = torch.empty(max(int(need), 16), dtype=torch.uint8, device=gpu)
+    _lib.check(lib.radad_linear_forward(xd.data_ptr(), n_in, wd.data_ptr(), n_in, bd.data_ptr(), act, rows, n_out, n_in,
+                                        out.data_ptr(), n_out, ws.data_ptr(), int(ws.numel()), xd.device.index,
+                                        _lib.stream_ptr(xd.device)), "radad_linear_forward")
+    want = x.astype(np.float64) @ w.astype(np.float64).T + b
+    want = np.tanh(want) if act == 1 else (np.maximum(want, 0) if act == 2 else want)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=0, atol=1e-4)
+    with pytest.raises(ValueError, match="multiples of 4"):
+        _lib.check(lib.radad_linear_forward(xd.data_ptr(), n_in, wd.data_ptr(), n_in, bd.data_ptr(), act, 1, n_out, n_in - 1,
+                                            out.data_ptr(), n_out, ws.data_ptr(), int(ws.numel()), xd.device.index,
+                                            _lib.stream_ptr(xd.device)), "radad_linear_forward")
+
+
 class _FakeDataset:
     """what process_audio_batch needs from AudioDataset: load_audio(path) -> float32 [N] (dataset.py:139-153)"""
 
