@@ -105,9 +105,16 @@ int radad_knn_search_host(radad_knn_t h, const float* q_host, int64_t nq, int k,
  * (the zero padding pipeline.py:511-512 applies) */
 int radad_knn_reconstruct(radad_knn_t h, const int64_t* idx_dev, int64_t n, float* out_dev, void* stream);
 int radad_knn_reconstruct_host(radad_knn_t h, const int64_t* idx_host, int64_t n, float* out_host);
-/* binary snapshot of the store (header + fp32 rows); load replaces the contents of h */
+/* binary snapshot of the store ("RADADKNN" header + rows as stored, fp32 or fp16); load replaces the contents of h
+ * (VectorDatabase.save / .load, vector_database.py:190-242).  Both directions stream through two pinned staging
+ * buffers on a private stream (file I/O overlaps the DMA); load maps the file read-only, so
+ * radad_knn_load_range -- rows [row0, row0 + n_rows) of the snapshot, n_rows < 0 = through the end -- touches only
+ * its own byte range: G ranks load one snapshot as G row shards (create each handle with id_base = row0). */
 int radad_knn_save(radad_knn_t h, const char* path);
 int radad_knn_load(radad_knn_t h, const char* path);
+int radad_knn_load_range(radad_knn_t h, const char* path, int64_t row0, int64_t n_rows);
+/* header of a snapshot without a handle (any out pointer may be NULL) */
+int radad_knn_snapshot_info(const char* path, int* dim_out, int* metric_out, int* store_dtype_out, int64_t* ntotal_out);
 /* seconds spent in the most recent search's kernels are NOT measured here; use HIP events on `stream`.
  * Query the launch geometry of the last search (for roofline accounting in bench.py). */
 int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, int* block_threads);

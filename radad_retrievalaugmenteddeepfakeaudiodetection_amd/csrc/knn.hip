@@ -22,6 +22,10 @@
 #include <new>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <vector>
 
 namespace {
@@ -1493,25 +1497,164 @@ int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, i
 
 // ---- snapshot: "RADADKNN" | u32 version (2) | i32 dim | i32 metric | i32 store dtype | i64 ntotal | rows as stored
 // (already normalised for cosine; fp32 or fp16).  Version 1 files (no dtype field, fp32 rows) are still read.
+}  // extern "C"
+
+namespace {
+
+constexpr uint32_t SNAP_VERSION = 2;
+constexpr size_t SNAP_STAGE_BYTES = 32ull << 20;   // two pinned staging buffers of this size per transfer
+
+struct SnapHeader {
+    uint32_t ver = 0;
+    int32_t dim = 0, metric = 0, dtype = RADAD_STORE_F32;
+    int64_t ntotal = 0;
+    size_t payload_off = 0;   // byte offset of row 0
+};
+
+// "RADADKNN" | u32 ver | i32 dim | i32 metric | [v2: i32 dtype] | i64 ntotal | rows
+bool snap_parse(const unsigned char* p, size_t len, SnapHeader* out) {
+    if (len < 28 || memcmp(p, "RADADKNN", 8) != 0) return false;
+    size_t o = 8;
+    memcpy(&out->ver, p + o, 4); o += 4;
+    if (out->ver != 1 && out->ver != 2) return false;
+    memcpy(&out->dim, p + o, 4); o += 4;
+    memcpy(&out->metric, p + o, 4); o += 4;
+    out->dtype = RADAD_STORE_F32;
+    if (out->ver >= 2) { memcpy(&out->dtype, p + o, 4); o += 4; }
+    if (len < o + 8) return false;
+    memcpy(&out->ntotal, p + o, 8); o += 8;
+    out->payload_off = o;
+    return out->dim > 0 && out->ntotal >= 0 && (out->dtype == RADAD_STORE_F32 || out->dtype == RADAD_STORE_F16);
+}
+
+// read-only mapping of a snapshot file; pages come in on demand, so a shard only touches its own byte range
+struct SnapMap {
+    int fd = -1;
+    const unsigned char* base = nullptr;
+    size_t len = 0;
+    ~SnapMap() {
+        if (base) munmap(const_cast<unsigned char*>(base), len);
+        if (fd >= 0) close(fd);
+    }
+    int open_ro(const char* path) {
+        fd = ::open(path, O_RDONLY);
+        if (fd < 0) { radad_set_error("cannot open %s", path); return RADAD_EIO; }
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size <= 0) { radad_set_error("%s: cannot stat / empty file", path); return RADAD_EIO; }
+        len = (size_t)st.st_size;
+        void* m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { radad_set_error("%s: mmap failed", path); return RADAD_EIO; }
+        base = static_cast<const unsigned char*>(m);
+        return RADAD_OK;
+    }
+};
+
+// two pinned buffers + a private stream: the CPU fills (or drains) one buffer while the DMA engine moves the other
+struct PinnedPipe {
+    char* buf[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    hipStream_t st = nullptr;
+    ~PinnedPipe() {
+        for (int i = 0; i < 2; ++i) {
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            if (buf[i]) (void)hipHostFree(buf[i]);
+        }
+        if (st) (void)hipStreamDestroy(st);
+    }
+    int init() {
+        RADAD_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            RADAD_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&buf[i]), SNAP_STAGE_BYTES, hipHostMallocDefault));
+            RADAD_HIP_CHECK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        }
+        return RADAD_OK;
+    }
+};
+
+int snap_load_range(radad_knn_t h, const char* path, int64_t row0, int64_t n_rows) {
+    SnapMap map;
+    int rc = map.open_ro(path);
+    if (rc) return rc;
+    SnapHeader hd;
+    const int32_t want = h->f16 ? RADAD_STORE_F16 : RADAD_STORE_F32;
+    if (!snap_parse(map.base, map.len, &hd) || hd.dim != h->dim || hd.metric != h->metric || hd.dtype != want) {
+        radad_set_error("%s: bad header or mismatch (file dim %d metric %d dtype %d, handle dim %d metric %d dtype %d)", path, hd.dim,
+                        hd.metric, hd.dtype, h->dim, h->metric, want);
+        return RADAD_EIO;
+    }
+    const size_t rb = h->row_bytes();
+    if (map.len < hd.payload_off + (size_t)hd.ntotal * rb) { radad_set_error("%s: truncated", path); return RADAD_EIO; }
+    if (n_rows < 0) n_rows = hd.ntotal - row0;
+    RADAD_REQUIRE(row0 >= 0 && n_rows >= 0 && row0 + n_rows <= hd.ntotal, "radad_knn_load_range: rows outside the snapshot");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    RADAD_HIP_CHECK(hipDeviceSynchronize());
+    h->ntotal = 0;
+    if ((rc = knn_grow(h, n_rows))) return rc;
+    const unsigned char* src = map.base + hd.payload_off + (size_t)row0 * rb;
+    const size_t total = (size_t)n_rows * rb;
+    if (total) {
+        (void)madvise(const_cast<unsigned char*>(map.base), map.len, MADV_SEQUENTIAL);
+        PinnedPipe pipe;
+        if ((rc = pipe.init())) return rc;
+        int slot = 0;
+        for (size_t off = 0; off < total; off += SNAP_STAGE_BYTES, slot ^= 1) {
+            const size_t m = std::min(SNAP_STAGE_BYTES, total - off);
+            RADAD_HIP_CHECK(hipEventSynchronize(pipe.done[slot]));      // the copy that last used this buffer has landed
+            memcpy(pipe.buf[slot], src + off, m);                       // page-in + stage; overlaps the other buffer's DMA
+            RADAD_HIP_CHECK(hipMemcpyAsync(h->rows + off, pipe.buf[slot], m, hipMemcpyHostToDevice, pipe.st));
+            RADAD_HIP_CHECK(hipEventRecord(pipe.done[slot], pipe.st));
+        }
+        RADAD_HIP_CHECK(hipStreamSynchronize(pipe.st));
+    }
+    if (h->metric == RADAD_METRIC_L2 && n_rows > 0) {      // |y|^2 is not part of the snapshot
+        const unsigned grid = (unsigned)ceil_div64(n_rows, 4);
+        if (h->f16) hipLaunchKernelGGL(k_row_sqnorm<_Float16>, dim3(grid), dim3(256), 0, nullptr, (const _Float16*)h->rows, n_rows, h->dim, h->ynorm);
+        else hipLaunchKernelGGL(k_row_sqnorm<float>, dim3(grid), dim3(256), 0, nullptr, (const float*)h->rows, n_rows, h->dim, h->ynorm);
+        RADAD_HIP_CHECK(hipGetLastError());
+        RADAD_HIP_CHECK(hipDeviceSynchronize());
+    }
+    h->ntotal = n_rows;
+    return RADAD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int radad_knn_save(radad_knn_t h, const char* path) {
     RADAD_REQUIRE(h && path, "radad_knn_save: NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
+    RADAD_HIP_CHECK(hipDeviceSynchronize());
     FILE* f = fopen(path, "wb");
     if (!f) { radad_set_error("cannot open %s for writing", path); return RADAD_EIO; }
     const char magic[8] = {'R', 'A', 'D', 'A', 'D', 'K', 'N', 'N'};
-    const uint32_t ver = 2;
+    const uint32_t ver = SNAP_VERSION;
     const int32_t dim = h->dim, metric = h->metric, dtype = h->f16 ? RADAD_STORE_F16 : RADAD_STORE_F32;
     const int64_t nt = h->ntotal;
     bool ok = fwrite(magic, 1, 8, f) == 8 && fwrite(&ver, 4, 1, f) == 1 && fwrite(&dim, 4, 1, f) == 1 &&
               fwrite(&metric, 4, 1, f) == 1 && fwrite(&dtype, 4, 1, f) == 1 && fwrite(&nt, 8, 1, f) == 1;
-    const size_t rb = h->row_bytes();
-    const int64_t chunk = std::max<int64_t>(1, (int64_t)((64ull << 20) / rb));
-    std::vector<char> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(nt, 1)) * rb);
-    for (int64_t r = 0; ok && r < nt; r += chunk) {
-        const int64_t m = std::min<int64_t>(chunk, nt - r);
-        if (hipMemcpy(buf.data(), h->rows + (size_t)r * rb, (size_t)m * rb, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
-        ok = fwrite(buf.data(), 1, (size_t)m * rb, f) == (size_t)m * rb;
+    const size_t total = (size_t)nt * h->row_bytes();
+    int rc = RADAD_OK;
+    if (ok && total) {
+        PinnedPipe pipe;
+        if ((rc = pipe.init())) { fclose(f); return rc; }
+        // D2H of chunk i+1 runs while chunk i is written to the file
+        auto fetch = [&](size_t off, int slot) {
+            const size_t m = std::min(SNAP_STAGE_BYTES, total - off);
+            if (hipMemcpyAsync(pipe.buf[slot], h->rows + off, m, hipMemcpyDeviceToHost, pipe.st) != hipSuccess) return false;
+            return hipEventRecord(pipe.done[slot], pipe.st) == hipSuccess;
+        };
+        int slot = 0;
+        ok = fetch(0, 0);
+        for (size_t off = 0; ok && off < total; off += SNAP_STAGE_BYTES, slot ^= 1) {
+            const size_t m = std::min(SNAP_STAGE_BYTES, total - off);
+            if (off + SNAP_STAGE_BYTES < total) ok = fetch(off + SNAP_STAGE_BYTES, slot ^ 1);
+            ok = ok && hipEventSynchronize(pipe.done[slot]) == hipSuccess;
+            ok = ok && fwrite(pipe.buf[slot], 1, m, f) == m;
+        }
+        (void)hipStreamSynchronize(pipe.st);
     }
     ok = (fclose(f) == 0) && ok;
     if (!ok) { radad_set_error("write to %s failed", path); return RADAD_EIO; }
@@ -1520,43 +1663,27 @@ int radad_knn_save(radad_knn_t h, const char* path) {
 
 int radad_knn_load(radad_knn_t h, const char* path) {
     RADAD_REQUIRE(h && path, "radad_knn_load: NULL argument");
+    return snap_load_range(h, path, 0, -1);
+}
+
+int radad_knn_load_range(radad_knn_t h, const char* path, int64_t row0, int64_t n_rows) {
+    RADAD_REQUIRE(h && path, "radad_knn_load_range: NULL argument");
+    return snap_load_range(h, path, row0, n_rows);
+}
+
+int radad_knn_snapshot_info(const char* path, int* dim_out, int* metric_out, int* store_dtype_out, int64_t* ntotal_out) {
+    RADAD_REQUIRE(path, "radad_knn_snapshot_info: NULL path");
     FILE* f = fopen(path, "rb");
     if (!f) { radad_set_error("cannot open %s", path); return RADAD_EIO; }
-    char magic[8]; uint32_t ver = 0; int32_t dim = 0, metric = 0, dtype = RADAD_STORE_F32; int64_t nt = 0;
-    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, "RADADKNN", 8) == 0 && fread(&ver, 4, 1, f) == 1 && (ver == 1 || ver == 2) &&
-              fread(&dim, 4, 1, f) == 1 && fread(&metric, 4, 1, f) == 1 && (ver == 1 || fread(&dtype, 4, 1, f) == 1) &&
-              fread(&nt, 8, 1, f) == 1;
-    const int32_t want = h->f16 ? RADAD_STORE_F16 : RADAD_STORE_F32;
-    if (!ok || dim != h->dim || metric != h->metric || dtype != want || nt < 0) {
-        fclose(f);
-        radad_set_error("%s: bad header or mismatch (file dim %d metric %d dtype %d, handle dim %d metric %d dtype %d)", path, dim,
-                        metric, dtype, h->dim, h->metric, want);
-        return RADAD_EIO;
-    }
-    std::lock_guard<std::mutex> lk(h->mu);
-    DeviceGuard g(h->device);
-    RADAD_HIP_CHECK(hipDeviceSynchronize());
-    h->ntotal = 0;
-    int rc = knn_grow(h, nt);
-    if (rc) { fclose(f); return rc; }
-    const size_t rb = h->row_bytes();
-    const int64_t chunk = std::max<int64_t>(1, (int64_t)((64ull << 20) / rb));
-    std::vector<char> buf((size_t)std::min<int64_t>(chunk, std::max<int64_t>(nt, 1)) * rb);
-    for (int64_t r = 0; r < nt; r += chunk) {
-        const int64_t m = std::min<int64_t>(chunk, nt - r);
-        if (fread(buf.data(), 1, (size_t)m * rb, f) != (size_t)m * rb) { fclose(f); radad_set_error("%s: truncated", path); return RADAD_EIO; }
-        hipError_t e = hipMemcpy(h->rows + (size_t)r * rb, buf.data(), (size_t)m * rb, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { fclose(f); radad_set_error("H2D copy failed: %s", hipGetErrorString(e)); return RADAD_EHIP; }
-    }
+    unsigned char head[32];
+    const size_t got = fread(head, 1, sizeof(head), f);
     fclose(f);
-    if (h->metric == RADAD_METRIC_L2 && nt > 0) {      // |y|^2 is not part of the snapshot
-        const unsigned grid = (unsigned)ceil_div64(nt, 4);
-        if (h->f16) hipLaunchKernelGGL(k_row_sqnorm<_Float16>, dim3(grid), dim3(256), 0, nullptr, (const _Float16*)h->rows, nt, h->dim, h->ynorm);
-        else hipLaunchKernelGGL(k_row_sqnorm<float>, dim3(grid), dim3(256), 0, nullptr, (const float*)h->rows, nt, h->dim, h->ynorm);
-        RADAD_HIP_CHECK(hipGetLastError());
-        RADAD_HIP_CHECK(hipDeviceSynchronize());
-    }
-    h->ntotal = nt;
+    SnapHeader hd;
+    if (!snap_parse(head, got, &hd)) { radad_set_error("%s: not a RADADKNN snapshot", path); return RADAD_EIO; }
+    if (dim_out) *dim_out = hd.dim;
+    if (metric_out) *metric_out = hd.metric;
+    if (store_dtype_out) *store_dtype_out = hd.dtype;
+    if (ntotal_out) *ntotal_out = hd.ntotal;
     return RADAD_OK;
 }
 

@@ -312,7 +312,7 @@ inline void split_plan(int64_t M, int N, int K, int* splits, int* chunks_per_spl
     int64_t want = ceil_div64(SPLIT_TARGET_BLOCKS, tiles);
     if (want < 1) want = 1;
     if (want > nk) want = nk;
-    const int cps = (int)ceil_div64(nk, want);
+    const int cps = (int)std::min<int64_t>(nk, std::max<int64_t>(4, ceil_div64(nk, want)));   // >= 4 chunks: the tail re-reads S partials
     *chunks_per_split = cps;
     *splits = (int)ceil_div64(nk, cps);
 }

@@ -185,8 +185,29 @@ class HipFlatIndex:
     def save(self, path: str):
         _lib.check(self._lib.radad_knn_save(self._h, os.fsencode(path)), "radad_knn_save")
 
-    def load(self, path: str):
-        _lib.check(self._lib.radad_knn_load(self._h, os.fsencode(path)), "radad_knn_load")
+    def load(self, path: str, row0: int = 0, n_rows: int = -1):
+        """replace the contents with rows [row0, row0+n_rows) of a snapshot (default: all of it).  A rank of a sharded
+        run loads its own slice of one shared file: HipFlatIndex.load_shard."""
+        _lib.check(self._lib.radad_knn_load_range(self._h, os.fsencode(path), int(row0), int(n_rows)), "radad_knn_load")
+
+    @staticmethod
+    def snapshot_info(path: str) -> dict:
+        """header of a snapshot file: {"d", "metric", "store_f16", "ntotal"}"""
+        d, m, t, n = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+        _lib.check(_lib.load().radad_knn_snapshot_info(os.fsencode(path), C.byref(d), C.byref(m), C.byref(t), C.byref(n)),
+                   "radad_knn_snapshot_info")
+        return {"d": d.value, "metric": m.value, "store_f16": t.value == _lib.STORE_F16, "ntotal": n.value}
+
+    @classmethod
+    def load_shard(cls, path: str, rank: int, world_size: int, device: int = 0):
+        """this rank's row shard of a snapshot written by any number of GPUs: rows shard_bounds(ntotal, world, rank),
+        ids reported globally (id_base = first row).  Only the shard's byte range of the file is read."""
+        from .sharded import shard_bounds
+        info = cls.snapshot_info(path)
+        lo, hi = shard_bounds(info["ntotal"], world_size, rank)
+        index = cls(info["d"], info["metric"], device=device, id_base=lo, store_f16=info["store_f16"])
+        index.load(path, lo, hi - lo)
+        return index
 
 
 class HipIVFFlatIndex:
@@ -476,7 +497,9 @@ class VectorDatabase:
             logging.error(f"Error saving vector database: {e}")
 
     # vector_database.py:218-242
-    def load(self):
+    def load(self, shard=None):
+        """shard=(rank, world_size): keep only this rank's row shard of the saved store (native snapshots only) -- the index
+        reads just its byte range of the file and reports global ids; paths / labels / metadata are cut to the same rows."""
         try:
             if not (os.path.exists(self.db_path) and os.path.exists(self.metadata_path)):
                 logging.warning("No saved vector database found")
@@ -484,8 +507,11 @@ class VectorDatabase:
             with open(self.metadata_path, "rb") as f:
                 meta = pickle.load(f)
             self.vector_paths, self.vector_labels, self.vector_metadata = meta["paths"], meta["labels"], meta["metadata"]
+            self._tags_host, self._tags_dev, self._labels_dev = [], None, None      # device columns follow the new rows
             with open(self.db_path, "rb") as f:
                 magic = f.read(8)
+            if shard is not None and magic != b"RADADKNN":
+                raise ValueError("sharded load is only available for native flat snapshots")
             if magic[:2] == b"PK":                      # numpy .npz: an IVF store written by save() above
                 z = np.load(self.db_path)
                 self.create_index(int(z["centroids"].shape[1]))
@@ -502,6 +528,19 @@ class VectorDatabase:
                 self.create_index(d)
                 for s0 in range(0, len(rows), 1 << 18):
                     self.index.add(rows[s0:s0 + (1 << 18)])
+            elif shard is not None:
+                from .sharded import shard_bounds
+                rank, world = int(shard[0]), int(shard[1])
+                self.create_index(int(meta["dimension"]))
+                if not isinstance(self.index, HipFlatIndex):
+                    raise ValueError("sharded load needs a flat store")
+                lo, hi = shard_bounds(HipFlatIndex.snapshot_info(self.db_path)["ntotal"], world, rank)
+                self.index = HipFlatIndex(self.index.d, self.index.metric, device=self.device_id, id_base=lo,
+                                          store_f16=self.index.store_f16)
+                self.index.load(self.db_path, lo, hi - lo)
+                self.vector_paths, self.vector_labels = self.vector_paths[lo:hi], self.vector_labels[lo:hi]
+                if isinstance(self.vector_metadata, dict):
+                    self.vector_metadata = {key: vals[lo:hi] for key, vals in self.vector_metadata.items()}
             else:
                 self.create_index(int(meta["dimension"]))
                 self.index.load(self.db_path)

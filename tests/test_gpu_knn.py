@@ -323,3 +323,45 @@ def test_load_store_written_in_faiss_flat_layout(gpu, tmp_path):
     np.testing.assert_array_equal(I, oi)
     with pytest.raises(ValueError):
         read_faiss_flat(os.path.join(cfg.vector_db_path, "metadata.pkl"))
+
+
+@pytest.mark.parametrize("store_f16", [False, True])
+def test_snapshot_loaded_as_row_shards(gpu, tmp_path, store_f16):
+    """one snapshot file, loaded as 3 row shards (each handle reads only its byte range, global ids via
+    id_base); merged shard results == the single-store search; whole-file load == original rows bit for bit."""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import hip_merge, shard_bounds
+    n, d, k = 5003, 96, 7
+    rows = torch.from_numpy(synth.rows(0, n, d, 808)).to(gpu)
+    q = torch.from_numpy(synth.rows(0, 33, d, 809)).to(gpu)
+    full = R.HipFlatIndex(d, _lib.METRIC_L2, device=0, store_f16=store_f16)
+    full.add_device(rows)
+    path = str(tmp_path / "store.radad")
+    full.save(path)
+    info = R.HipFlatIndex.snapshot_info(path)
+    assert info == {"d": d, "metric": _lib.METRIC_L2, "store_f16": store_f16, "ntotal": n}
+    assert os.path.getsize(path) == 32 + n * d * (2 if store_f16 else 4)
+    D0, I0, K0 = full.search_device(q, k, return_f64=True)
+    again = R.HipFlatIndex(d, _lib.METRIC_L2, device=0, store_f16=store_f16)
+    again.load(path)
+    ids = torch.arange(n, device=gpu)
+    assert torch.equal(again.reconstruct_batch(ids), full.reconstruct_batch(ids))
+    parts = [R.HipFlatIndex.load_shard(path, r, 3, device=0) for r in range(3)]
+    assert [p.ntotal for p in parts] == [hi - lo for lo, hi in (shard_bounds(n, 3, r) for r in range(3))]
+    res = [p.search_device(q, k, return_f64=True) for p in parts]
+    Dm, Im = hip_merge(_lib.METRIC_L2, torch.stack([r[2] for r in res]), torch.stack([r[1] for r in res]), k)
+    assert torch.equal(Im, I0)
+    np.testing.assert_allclose(Dm.cpu().numpy(), D0.cpu().numpy(), rtol=1e-6)
+    lo, hi = shard_bounds(n, 3, 1)
+    assert torch.equal(parts[1].reconstruct_batch(torch.arange(lo, hi, device=gpu)), full.reconstruct_batch(torch.arange(lo, hi, device=gpu)))
+    with pytest.raises(ValueError, match="outside the snapshot"):
+        again.load(path, n - 5, 6)
+    empty = R.HipFlatIndex(d, _lib.METRIC_L2, device=0, store_f16=store_f16)
+    empty.load(path, 17, 0)
+    assert empty.ntotal == 0
+    with open(path, "r+b") as f:
+        f.truncate(os.path.getsize(path) - 4)
+    with pytest.raises(OSError, match="truncated"):
+        again.load(path)

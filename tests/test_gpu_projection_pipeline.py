@@ -292,3 +292,38 @@ def test_build_vector_database_streams_on_device(gpu, tmp_path):
     v2 = R.VectorDatabase(cfg)
     v2.load()                                                   # build_vector_database saved it
     assert v2.index.ntotal == 10
+
+
+def test_vector_database_sharded_load(gpu, tmp_path):
+    """VectorDatabase.load(shard=(rank, world)): two shards of one saved store answer like the whole store after the merge,
+    and carry the matching slice of paths / labels."""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import hip_merge, shard_bounds
+    d, n = 64, 1001
+    cfg = R.Config()
+    cfg.update(device=gpu, vector_db_index_type="IP", vector_db_path=str(tmp_path / "vdb"))
+    whole = R.VectorDatabase(cfg)
+    whole.create_index(d)
+    rows = synth.rows(0, n, d, 515)
+    whole.add_vectors(rows, [f"/data/f{i}.wav" for i in range(n)], [i % 2 for i in range(n)], {"i": list(range(n))})
+    whole.save()
+    q = torch.from_numpy(synth.rows(0, 20, d, 516)).to(gpu)
+    qn = torch.nn.functional.normalize(q, dim=1)
+    D0, I0, _ = whole.index.search_device(qn, 5, return_f64=True)
+    keys, ids = [], []
+    for r in range(2):
+        part = R.VectorDatabase(cfg)
+        part.load(shard=(r, 2))
+        lo, hi = shard_bounds(n, 2, r)
+        assert part.index.ntotal == hi - lo and part.index.id_base == lo
+        assert part.vector_paths == whole.vector_paths[lo:hi] and part.vector_labels == whole.vector_labels[lo:hi]
+        assert part.vector_metadata == {"i": list(range(lo, hi))}
+        assert part.labels_device().numel() == hi - lo
+        _, i, k64 = part.index.search_device(qn, 5, return_f64=True)
+        keys.append(k64)
+        ids.append(i)
+    Dm, Im = hip_merge(_lib.METRIC_COSINE, torch.stack(keys), torch.stack(ids), 5)
+    assert torch.equal(Im, I0)
+    np.testing.assert_allclose(Dm.cpu().numpy(), D0.cpu().numpy(), rtol=0, atol=1e-6)
