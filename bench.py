@@ -10,7 +10,8 @@ Workload (BASELINE.json metric: "clips/sec (segment+embed+retrieve) @1M x 512 DB
   therefore constant in N ("weak"); value = N*1024 clips / max-over-ranks step time.
 
 One JSON line on rank 0 (contract in the task statement), including
-  roofline     : the dominant kernel (k_knn_f32, fp32 MFMA bound) timed with HIP events on the launch stream
+  roofline     : the dominant kernel (the scan: k_knn_wide on the f16 matrix pipe, or k_knn_f32_reg with --scan f32)
+                 timed with HIP events on the launch stream
   cpu_baseline : the oracle (numpy port of the same pipeline) timed on this host on a bounded sample,
                  which doubles as the full-size parity check of the GPU result (ids bit-exact on the sample).
 """
@@ -31,12 +32,15 @@ DIM = 512
 TOP_K = 10
 AUDIO_SEED, DB_SEED, NOISE_SEED = 1234, 4321, 99
 PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
+PEAK_MFMA_F16_TFLOPS = 2500.0     # same guide: BF16/F16 MFMA ~2.5 PF dense (at 2.4 GHz; MFMA-dense loops hold 1.5-1.95 GHz)
 PEAK_HBM_GBPS = 8000.0
 # HBM-side bytes of ONE scan launch of the default 1-GPU workload, from the PMC passes of the same command
 # (profiles/r1_b_pmc_summary.txt, tools/profile_r1.sh): FETCH_SIZE 4.184e6 KB x 1024 x 2 (gfx950 reports half of a
 # 16-B/lane stream, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 8.2e3 KB x 1024.  Infinity-Cache hits are counted in
 # FETCH_SIZE, so this is an upper bound on DRAM traffic; it is only meaningful for that exact workload.
 SCAN_TRAFFIC_BYTES_R1B = 4.18399e6 * 1024 * 2 + 8195.59 * 1024
+# the same for k_knn_wide (profiles/r1_d_pmc_summary.txt): FETCH_SIZE 1.508e6 KB, WRITE_SIZE 3.19e4 KB per full-scan launch
+SCAN_TRAFFIC_BYTES_WIDE = 1.508e6 * 1024 * 2 + 3.193e4 * 1024
 
 
 def planted_row(j, c, n_total):
@@ -55,9 +59,14 @@ def main():
     ap.add_argument("--workload", choices=["fixed", "ragged"], default="fixed",
                     help="fixed = 4 s clips (the headline); ragged = BASELINE config 3: release_in_the_wild-shaped variable-length "
                          "clips (log-normal, mean ~4.3 s, clipped to [0.5, 20] s) cut by the segmenter rule")
+    ap.add_argument("--scan", choices=["auto", "f32"], default="auto",
+                    help="auto = large batches scan on the f16 matrix pipe (split-f16 copy of the fp32 store, 3 MFMAs per fp32 "
+                         "product, float64 re-rank from the fp32 rows); f32 = the fp32-MFMA tile kernel (RADAD_KNN_SPLIT=0)")
     ap.add_argument("--store-dtype", choices=["f32", "f16"], default="f32",
                     help="f16 = the reference's use_float16 knob (fp16 rows, fp16 MFMA scan); NOT the headline configuration")
     args = ap.parse_args()
+    if args.scan == "f32":
+        os.environ["RADAD_KNN_SPLIT"] = "0"       # read by radad_knn_create
 
     import numpy as np
     import torch
@@ -185,14 +194,29 @@ def main():
     alg_bytes = 4.0 * (hi - lo) * DIM + 4.0 * Q * DIM + 12.0 * Q * TOP_K
     achieved = flops / (knn_avg * 1e-3) / 1e12
     f16 = args.store_dtype == "f16"
-    peak = 2500.0 if f16 else PEAK_MFMA_F32_TFLOPS           # dense fp16 MFMA ~2.5 PFLOP/s (MI355X_MICROARCH.md)
+    launch = vdb.index.last_launch()
+    wide = launch["block_threads"] == 512                     # k_knn_wide (knn_wide.inc) took the scan
     if f16:
         alg_bytes = 2.0 * (hi - lo) * DIM + 2.0 * Q * DIM + 12.0 * Q * TOP_K
+    if wide:
+        kname = "k_knn_wide<16,%d>" % (1 if f16 else 0)
+        peak = PEAK_MFMA_F16_TFLOPS
+        issued = flops * (1.0 if f16 else 3.0)                # split form: 3 f16 MFMA products per fp32 product
+        dtype = ("f32 embed; f16 store + f16 MFMA scan (f32 accumulate, f64 re-rank)" if f16 else
+                 "f32 (scan products as 3 f16 MFMAs on hi/lo splits of the fp32 values, f32 accumulate; f64 re-rank from the fp32 rows)")
+    else:
+        kname = "k_knn_f32_reg<16,%s>" % ("true" if f16 else "false")
+        peak = PEAK_MFMA_F16_TFLOPS if f16 else PEAK_MFMA_F32_TFLOPS
+        issued = flops
+        dtype = "f32" if not f16 else "f32 embed; f16 store + f16 MFMA scan (f32 accumulate, f64 re-rank)"
+    traffic = None
+    if world == 1 and B == CLIPS_PER_GPU and n_total == DB_ROWS and not f16 and args.workload == "fixed":
+        traffic = SCAN_TRAFFIC_BYTES_WIDE if wide else SCAN_TRAFFIC_BYTES_R1B
     out = {
         "metric": "clips/sec (segment+embed+retrieve) @1Mx512 DB",
         "value": round(value, 1), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.store_dtype == "f32" else "f32 embed; f16 store + f16 MFMA scan (f32 accumulate, f64 re-rank)",
+        "dtype": dtype,
         "data": "synthetic",
         "config": {"workload": (f"{B} clips/GPU x 4 s @16 kHz (3 segments)" if args.workload == "fixed" else
                                 f"{B} variable-length clips/GPU (log-normal, mean {float(np.mean(np.diff(offsets))) / 16000:.2f} s, "
@@ -201,14 +225,15 @@ def main():
                                f"row-sharded over {world} GPU(s)", "segments_per_gpu": n_segments,
                    "clips_per_gpu": B, "db_rows": n_total, "dim": DIM, "k": TOP_K, "parallelism": f"shard{world}",
                    "planted_neighbours_found": planted_ok},
-        "roofline": {"kernel": "k_knn_f32_reg<16,%s>" % ("true" if f16 else "false"), "bound": "mfma", "achieved": round(achieved, 2),
+        "roofline": {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 2),
                      "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": SCAN_TRAFFIC_BYTES_R1B if (world == 1 and B == CLIPS_PER_GPU and n_total == DB_ROWS and not f16) else None,
+                     "traffic": traffic,
+                     "mfma_flops_issued_per_launch": issued, "issued_frac": round(issued / (knn_avg * 1e-3) / 1e12 / peak, 4),
                      "kernel_ms": round(knn_avg, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
                      "hbm_GBps_algorithmic": round(alg_bytes / (knn_avg * 1e-3) / 1e9, 1),
-                     "launch": vdb.index.last_launch()},
+                     "launch": launch},
         "kernels_ms": {"k_logmel": round(float(np.mean(lm_ms)), 4) if lm_ms else None,
-                       "k_proj_pool": round(float(np.mean(pp_ms)), 4) if pp_ms else None, "k_knn_f32": round(knn_avg, 4)},
+                       "k_proj_pool": round(float(np.mean(pp_ms)), 4) if pp_ms else None, "scan": round(knn_avg, 4)},
     }
 
     # ---- CPU baseline = the oracle on this host, bounded sample; also the full-size parity check ------------------

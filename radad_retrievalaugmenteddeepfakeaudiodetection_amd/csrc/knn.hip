@@ -599,7 +599,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
         if (*s_flag == 0) {
             // common case: nothing overflowed.  The drain is deferred into the next tile's K loop (or done right here
             // for the last tile); no second barrier, the next K loop's own barriers order everything.
-            if (has_next) pending = true;
+            if (has_next && dc.nk >= 2) pending = true;     // nk == 1: the only K-loop barrier precedes the drain hook
             else drain();
             continue;
         }
@@ -646,6 +646,8 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
             if (j < p.k) { ls[j] = key_score(lst[j]); li[j] = key_id(lst[j]); }
     }
 }
+
+#include "knn_wide.inc"
 
 // ---- small-batch scan (nq <= 16: the online `predict` case, pipeline.py:1038-1054) ------------------------------
 // With a handful of queries the scan is HBM-bound (2 flop per stored byte per query), so the 128-query tile above
@@ -797,6 +799,7 @@ constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float2)
 //   identical in both precisions and resolves to the lower id either way).
 // k_merge_lists<KeyT> (radad_topk_merge / _f64): plain P-way merge of final per-shard lists, no rescoring.
 constexpr int KNN_MARGIN = 6;
+constexpr int KW_SAMPLE_ROWS = 4096;   // rows of the threshold pre-pass of the wide kernel (16 one-tile splits)
 
 struct RefineParams {
     const float* score;       // [nq, n_parts, ksel] fp32 scan scores (larger is better)
@@ -1095,12 +1098,17 @@ struct radad_knn_s {
     int f16 = 0;              // 1: rows are stored as IEEE fp16 (config.use_float16, vector_database.py:80)
     char* rows = nullptr;     // [capacity, dim] fp32 or fp16
     float* ynorm = nullptr;
+    // split-f16 copy of an fp32 store for the wide scan (knn_wide.inc): built lazily, rows [0, split_rows) are current
+    _Float16* split = nullptr;   // [split_cap][dim/32][hi32|lo32]
+    float* rscale = nullptr;     // [split_cap] 2^-e per row
+    int64_t split_rows = 0, split_cap = 0;
+    int split_off = 0;           // 1: disabled (RADAD_KNN_SPLIT=0, or its allocation failed)
     size_t esize() const { return f16 ? 2 : 4; }
     size_t row_bytes() const { return (size_t)dim * esize(); }
     // search workspace (grown on demand, reused)
     void* ws = nullptr;
     size_t ws_bytes = 0;
-    int last_qtiles = 0, last_splits = 0;
+    int last_qtiles = 0, last_splits = 0, last_threads = KNN_THREADS;
     EventRing prof;
     std::mutex mu;
 };
@@ -1126,6 +1134,9 @@ static int knn_realloc(radad_knn_t h, int64_t cap) {
     h->rows = nrows;
     h->ynorm = nnorm;
     h->capacity = cap;
+    if (h->split) (void)hipFree(h->split);       // rebuilt lazily for the new capacity
+    if (h->rscale) (void)hipFree(h->rscale);
+    h->split = nullptr; h->rscale = nullptr; h->split_rows = 0; h->split_cap = 0;
     return RADAD_OK;
 }
 
@@ -1149,6 +1160,49 @@ static int knn_workspace(radad_knn_t h, size_t bytes) {
     return RADAD_OK;
 }
 
+// bring the split-f16 copy up to date with the fp32 rows (appends only touch the new rows); false = not available
+static bool knn_ensure_split(radad_knn_t h, hipStream_t st) {
+    if (h->split_off || h->f16 || h->dim % 32 != 0) return false;
+    if (h->split_cap != h->capacity || !h->split) {
+        (void)hipStreamSynchronize(st);
+        if (h->split) (void)hipFree(h->split);
+        if (h->rscale) (void)hipFree(h->rscale);
+        h->split = nullptr; h->rscale = nullptr; h->split_rows = 0; h->split_cap = 0;
+        if (hipMalloc(&h->split, (size_t)h->capacity * h->dim * 4) != hipSuccess ||
+            hipMalloc(&h->rscale, (size_t)h->capacity * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->split) (void)hipFree(h->split);
+            h->split = nullptr; h->rscale = nullptr;
+            h->split_off = 1;           // no room for the second copy: stay on the fp32 tile kernel
+            return false;
+        }
+        h->split_cap = h->capacity;
+    }
+    if (h->split_rows < h->ntotal) {
+        const int64_t m = h->ntotal - h->split_rows;
+        hipLaunchKernelGGL(k_split_rows, dim3((unsigned)ceil_div64(m, 4)), dim3(256), 0, st,
+                           (const float*)h->rows + (size_t)h->split_rows * h->dim, h->split + (size_t)h->split_rows * h->dim * 2,
+                           h->rscale + h->split_rows, m, h->dim);
+        if (hipGetLastError() != hipSuccess) return false;
+        h->split_rows = h->ntotal;
+    }
+    return true;
+}
+
+// wide kernel: 256-query tiles, one workgroup per CU; two rounds of workgroups keep the tail short
+static void knn_geometry_wide(int64_t n, int64_t nq, int* n_qtiles, int* n_splits, int64_t* chunk_rows) {
+    const int qt = (int)ceil_div64(nq, KW_N);
+    const int64_t tiles = ceil_div64(n, KW_M);
+    int64_t want = ceil_div64(512, qt);
+    want = std::min<int64_t>(want, tiles);
+    want = std::max<int64_t>(8, ceil_div64(want, 8) * 8);
+    want = std::min<int64_t>(want, 1024);
+    const int64_t tiles_per = ceil_div64(tiles, want);
+    *n_qtiles = qt;
+    *n_splits = (int)want;
+    *chunk_rows = tiles_per * KW_M;
+}
+
 extern "C" {
 
 int radad_knn_create(int dim, int metric, int device, int64_t id_base, radad_knn_t* out) {
@@ -1166,6 +1220,7 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
     radad_knn_s* h = new (std::nothrow) radad_knn_s();
     if (!h) { radad_set_error("out of host memory"); return RADAD_ENOMEM; }
     h->dim = dim; h->metric = metric; h->device = device; h->id_base = id_base; h->f16 = store_dtype == RADAD_STORE_F16;
+    { const char* e = getenv("RADAD_KNN_SPLIT"); h->split_off = (e && atoi(e) == 0) ? 1 : 0; }
     *out = h;
     return RADAD_OK;
 }
@@ -1177,6 +1232,8 @@ int radad_knn_destroy(radad_knn_t h) {
         if (h->rows) (void)hipFree(h->rows);
         if (h->ynorm) (void)hipFree(h->ynorm);
         if (h->ws) (void)hipFree(h->ws);
+        if (h->split) (void)hipFree(h->split);
+        if (h->rscale) (void)hipFree(h->rscale);
         h->prof.destroy();
     }
     delete h;
@@ -1288,6 +1345,14 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
     int n_qtiles, n_splits;
     int64_t chunk_rows;
     knn_geometry(std::max<int64_t>(h->ntotal, 1), nq, &n_qtiles, &n_splits, &chunk_rows);
+    // large batches take the wide kernel on the f16 matrix pipe: split-f16 copy of an fp32 store (mode 0) or the fp16
+    // store as it is (mode 1); see knn_wide.inc.  RADAD_KNN_SPLIT=0 keeps an fp32 store on the fp32 tile kernel.
+    int wide_mode = -1;
+    if (nq > KT_N && k + margin <= 32 && h->ntotal > 0) {
+        if (h->f16) { if (h->dim % 64 == 0) wide_mode = 1; }
+        else if (knn_ensure_split(h, st)) wide_mode = 0;
+    }
+    if (wide_mode >= 0) knn_geometry_wide(h->ntotal, nq, &n_qtiles, &n_splits, &chunk_rows);
     // small batches (the online predict case) take the HBM-bound streaming kernel: one list per WAVE
     const bool smallq = !h->f16 && nq <= SQ_NQ && h->dim % 32 == 0 && h->dim <= SQ_MAX_DIM && k + margin <= 32 && h->ntotal > 0;
     int sq_rows_per_wave = 0;
@@ -1300,12 +1365,17 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
         n_qtiles = 1;
     }
     h->last_qtiles = n_qtiles;
+    h->last_threads = wide_mode >= 0 ? KW_THREADS : (smallq ? SQ_THREADS : KNN_THREADS);
     h->last_splits = n_splits;
 
     // workspace: [qn: nq*dim fp32] (cosine) | [qh: nq*dim fp16] (fp16 store) | part_score | part_idx
     const size_t qn_bytes = h->metric == RADAD_METRIC_COSINE ? (size_t)nq * h->dim * sizeof(float) : 0;
-    const size_t qnorm_bytes = h->f16 ? ((((size_t)nq * h->dim * 2) + 255) & ~(size_t)255) : 256;
-    const size_t part_elems = (size_t)nq * n_splits * (k + margin);
+    // [qh]: fp16 queries (fp16 store) or split-f16 queries + their scales (wide kernel on an fp32 store)
+    const size_t qsplit_bytes = (((size_t)nq * h->dim * 4) + 255) & ~(size_t)255;
+    const size_t qvec_bytes = (((size_t)nq * sizeof(float)) + 255) & ~(size_t)255;
+    const size_t qnorm_bytes = (wide_mode == 0 ? qsplit_bytes + qvec_bytes
+                                               : (h->f16 ? ((((size_t)nq * h->dim * 2) + 255) & ~(size_t)255) : 256)) + qvec_bytes;
+    const size_t part_elems = (size_t)nq * std::max(n_splits, wide_mode >= 0 ? KW_SAMPLE_ROWS / KW_M : 0) * (k + margin);   // the sample pre-pass has 16 splits
     const size_t off_qnorm = (qn_bytes + 255) & ~(size_t)255;
     const size_t off_ps = off_qnorm + qnorm_bytes;
     const size_t off_pi = off_ps + ((part_elems * sizeof(float) + 255) & ~(size_t)255);
@@ -1332,7 +1402,11 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
     // (normalised) queries; the float64 re-rank below still uses the fp32 queries against the decoded rows.
     const int ksel = k + margin;                 // the scan keeps a few spare candidates for the float64 re-rank
     const bool f16_tile = h->f16 && ksel <= 32 && h->dim % 64 == 0;
-    if (f16_tile)
+    float* qscale = (float*)(ws + off_qnorm + qsplit_bytes);
+    float* thr_init = (float*)(ws + off_ps - qvec_bytes);      // last slot of the [qh] region
+    if (wide_mode == 0)
+        hipLaunchKernelGGL(k_split_rows, dim3(rgrid), dim3(256), 0, st, q_use, qh, qscale, nq, h->dim);
+    else if (f16_tile)
         hipLaunchKernelGGL(k_rows_prepare<_Float16>, dim3(rgrid), dim3(256), 0, st, q_use, qh, (float*)nullptr, nq, h->dim, 0);
     RADAD_HIP_CHECK(hipGetLastError());
 
@@ -1344,7 +1418,56 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
     // > 64 KB of dynamic LDS: raise the limit (per device, so on every call).  Lists live in registers when
     // k + margin fits 16 or 32 entries (k <= 26), otherwise in the partial-result arrays (generic kernel).
     const dim3 grid((unsigned)(n_qtiles * n_splits));
-    if (smallq) {
+    if (wide_mode >= 0) {
+        KnnWideParams wp;
+        wp.db = wide_mode == 0 ? (const void*)h->split : (const void*)h->rows;
+        wp.rscale = wide_mode == 0 ? h->rscale : nullptr;
+        wp.ynorm = h->ynorm; wp.q = qh; wp.qscale = wide_mode == 0 ? qscale : nullptr;
+        wp.n = h->ntotal; wp.nq = (int)nq; wp.row_bytes = h->dim * (wide_mode == 0 ? 4 : 2); wp.k = ksel; wp.l2 = p.l2;
+        wp.n_qtiles = n_qtiles; wp.n_splits = n_splits; wp.chunk_rows = chunk_rows; wp.part_score = ps; wp.part_idx = pi;
+        wp.thr_init = nullptr;
+        wp.debug = p.debug;
+        // <list entries, mode>: k + margin <= 16 / 24 / 32
+        const int kvar = ksel <= 16 ? 0 : (ksel <= 24 ? 1 : 2);
+        const void* fns[3][2] = {{reinterpret_cast<const void*>(k_knn_wide<16, 0>), reinterpret_cast<const void*>(k_knn_wide<16, 1>)},
+                                 {reinterpret_cast<const void*>(k_knn_wide<24, 0>), reinterpret_cast<const void*>(k_knn_wide<24, 1>)},
+                                 {reinterpret_cast<const void*>(k_knn_wide<32, 0>), reinterpret_cast<const void*>(k_knn_wide<32, 1>)}};
+        RADAD_HIP_CHECK(hipFuncSetAttribute(fns[kvar][wide_mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
+        auto launch = [&](const KnnWideParams& kp) {
+            const dim3 g((unsigned)(kp.n_qtiles * kp.n_splits));
+            const dim3 b(KW_THREADS);
+            const size_t lds = knn_wide_lds_bytes();
+            if (kvar == 0 && wide_mode == 0) hipLaunchKernelGGL((k_knn_wide<16, 0>), g, b, lds, st, kp);
+            else if (kvar == 0) hipLaunchKernelGGL((k_knn_wide<16, 1>), g, b, lds, st, kp);
+            else if (kvar == 1 && wide_mode == 0) hipLaunchKernelGGL((k_knn_wide<24, 0>), g, b, lds, st, kp);
+            else if (kvar == 1) hipLaunchKernelGGL((k_knn_wide<24, 1>), g, b, lds, st, kp);
+            else if (wide_mode == 0) hipLaunchKernelGGL((k_knn_wide<32, 0>), g, b, lds, st, kp);
+            else hipLaunchKernelGGL((k_knn_wide<32, 1>), g, b, lds, st, kp);
+        };
+        // sample pre-pass: the ksel-th best score over the first KW_SAMPLE_ROWS rows is a score at least ksel rows reach,
+        // so the full scan may start from it instead of -inf (scores of a (row, query) pair do not depend on the tiling).
+        // It reuses the head of the partial arrays; the full scan overwrites them afterwards.
+        if (h->ntotal >= 8 * KW_SAMPLE_ROWS && !(p.debug & 16)) {
+            KnnWideParams sp = wp;
+            sp.n = KW_SAMPLE_ROWS; sp.n_splits = KW_SAMPLE_ROWS / KW_M; sp.chunk_rows = KW_M;
+            const dim3 sg((unsigned)(sp.n_qtiles * sp.n_splits));
+            if (wide_mode == 0) {
+                RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_wide_sample<0>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
+                hipLaunchKernelGGL(k_knn_wide_sample<0>, sg, dim3(KW_THREADS), knn_wide_lds_bytes(), st, sp);
+            } else {
+                RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_wide_sample<1>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
+                hipLaunchKernelGGL(k_knn_wide_sample<1>, sg, dim3(KW_THREADS), knn_wide_lds_bytes(), st, sp);
+            }
+            hipLaunchKernelGGL(k_thr_from_parts<32>, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, st, ps, pi, sp.n_splits, ksel, nq,
+                               thr_init);
+            wp.thr_init = thr_init;
+        }
+        h->prof.begin(st);          // the event pair brackets the full-scan launch only (the kernel the roofline is quoted on)
+        launch(wp);
+        h->prof.end(st);
+    } else if (smallq) {
         SmallQParams sp;
         sp.db = (const float*)h->rows; sp.ynorm = h->ynorm; sp.q = q_use; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel;
         sp.l2 = p.l2; sp.rows_per_wave = sq_rows_per_wave; sp.n_parts = n_splits; sp.part_score = ps; sp.part_idx = pi;
@@ -1491,7 +1614,7 @@ int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, i
     RADAD_REQUIRE(h, "NULL handle");
     if (n_query_tiles) *n_query_tiles = h->last_qtiles;
     if (n_db_splits) *n_db_splits = h->last_splits;
-    if (block_threads) *block_threads = KNN_THREADS;
+    if (block_threads) *block_threads = h->last_threads;
     return RADAD_OK;
 }
 

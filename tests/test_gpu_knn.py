@@ -72,6 +72,63 @@ def test_knn_kernel_variants(gpu, metric, n, nq, dim, k):
     _check(D, I, od, oi, metric, unit=(metric == "COSINE"))
 
 
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
+@pytest.mark.parametrize("n,nq,dim,k,f16", [(40000, 257, 96, 10, False),    # sample pre-pass on (n >= 32768), ragged query tile
+                                            (9000, 700, 512, 15, False),    # reference k_search = 15 -> 24-entry lists
+                                            (5000, 130, 32, 24, False),     # one K step per tile, 32-entry lists
+                                            (33000, 300, 64, 10, True),     # fp16 store through the same kernel
+                                            (1000, 513, 128, 3, False)])    # fewer rows than one split of tiles
+def test_knn_wide_kernel(gpu, metric, n, nq, dim, k, f16):
+    """nq > 128: the 256 x 256 tile kernel on the f16 matrix pipe (knn_wide.inc) -- split-f16 copy of an fp32 store with
+    per-row power-of-two scales, or the fp16 store itself.  It only filters; ids must still equal the float64 oracle."""
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    db = synth.rows(0, n, dim, 2001)
+    q = synth.rows(0, nq, dim, 2002)
+    # rows of very different magnitude (the per-row scale has to cope) -- not for cosine, where rows are normalised anyway
+    if metric != "COSINE" and not f16:
+        db *= np.exp2(np.arange(n) % 23 - 11).astype(np.float32)[:, None]
+        q *= np.exp2(np.arange(nq) % 7 - 3).astype(np.float32)[:, None]
+    for j in range(nq):
+        db[(j * 17 + 3) % n] = q[j] + np.float32(0.1) * synth.rows(j, 1, dim, 2003)[0]
+    m = {"L2": _lib.METRIC_L2, "IP": _lib.METRIC_IP, "COSINE": _lib.METRIC_COSINE}[metric]
+    idx = HipFlatIndex(dim, m, 0, 0, store_f16=f16)
+    idx.add(db[: n // 3])
+    D0, I0 = idx.search(q, k)                      # builds the split copy of the first third
+    idx.add(db[n // 3:])                           # appended rows: only they are split on the next search
+    D, I = idx.search(q, k)
+    # judged on the rows AS STORED (normalised / rounded to fp16 by the add kernel): reconstruct is bit-exact
+    import torch
+    rec = idx.reconstruct_batch(torch.arange(n, device=gpu)).cpu().numpy()
+    om = "IP" if metric == "COSINE" else metric
+    qq = q.astype(np.float64)
+    if metric == "COSINE":
+        qq = qq / np.sqrt((qq ** 2).sum(1))[:, None]           # ranking does not depend on the query's scale
+    od, oi = O.knn(rec, qq, k, om)
+    np.testing.assert_array_equal(I, oi)
+    np.testing.assert_allclose(D, od, rtol=1e-5, atol=1e-5)
+    od3, oi3 = O.knn(rec[: n // 3], qq, k, om)
+    np.testing.assert_array_equal(I0, oi3)
+    assert idx.last_launch()["block_threads"] == 512
+
+
+def test_knn_wide_kernel_equals_fp32_tile_kernel(gpu, monkeypatch):
+    """RADAD_KNN_SPLIT=0 keeps an fp32 store on the fp32 tile kernel; both paths return identical ids and distances
+    (the float64 re-rank decides both)."""
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    n, nq, dim, k = 20000, 400, 256, 10
+    db = synth.rows(0, n, dim, 2101)
+    q = synth.rows(0, nq, dim, 2102)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("RADAD_KNN_SPLIT", flag)
+        idx = HipFlatIndex(dim, _lib.METRIC_L2, 0, 0)
+        idx.add(db)
+        res.append(idx.search(q, k) + (idx.last_launch()["block_threads"],))
+    assert (res[0][2], res[1][2]) == (512, 256)
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+
+
 def test_knn_empty_store(gpu):
     idx = _mk(gpu, "L2", 32)
     D, I = idx.search(synth.rows(0, 3, 32, 1), 4)
