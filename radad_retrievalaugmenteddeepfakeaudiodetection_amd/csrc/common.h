@@ -29,6 +29,8 @@ void radad_set_error(const char* fmt, ...);
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // RAII device switch: every entry point runs on the handle's device and restores the caller's.
 struct DeviceGuard {

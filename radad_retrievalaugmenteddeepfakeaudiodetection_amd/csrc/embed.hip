@@ -74,7 +74,8 @@ struct LogmelParams {
     int normalize;
     int padded;                  // P: virtual length after zero padding (== L in self mode)
     int nf;                      // frames actually computed per segment (<= 224)
-    const float* basis;          // [NBT][NKK][2][64][4]
+    const float* basis;          // [NBT][NKK][2][64][4]                      (k_logmel: folded fp32 basis)
+    const _Float16* basis_h;     // [NBT*25][cos_hi, cos_lo, sin_hi, sin_lo][64][8]  (k_logmel_h: split-f16 basis x 2^11)
     const float* fbfrag;         // [NBT][NMT][16][64]
     unsigned nzmask;             // bit (bt*NMT+mt): that (bin tile, mel tile) block of the filter bank is non-zero
     float* logmel;               // [S][nf][80] log10(max(mel,1e-10))  (before the max-8 clamp)
@@ -263,6 +264,8 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
     lmax = wave_max(lmax);
     if (lane == 0 && lmax > -INFINITY) atomic_max_float(p.seg_max + s, lmax);
 }
+
+#include "logmel_h.inc"
 
 // ---- projection + pooling -----------------------------------------------------------------------------
 // WAVES x 32 features per workgroup: 16 waves (all 512 features of the benchmark: each segment's log-mel is staged once
@@ -519,6 +522,8 @@ struct radad_embed_s {
     int nbins = 0, T = 0, nf = 0, padded = 0;
     unsigned nzmask = 0;
     float *basis = nullptr, *fbfrag = nullptr, *wfrag = nullptr, *bias = nullptr;
+    _Float16* basis_h = nullptr;
+    int logmel_f32 = 0;                  // RADAD_LOGMEL_F32=1: the fp32-MFMA kernel (k_logmel) instead of k_logmel_h
     int* levels_dev = nullptr;
     // plan cache + scratch
     std::vector<int64_t> plan_key;       // the clip_offsets the cached plan was built from
@@ -612,12 +617,13 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     LogmelParams p;
     p.wave = wave_dev; p.seg_start = (const int64_t*)h->seg_start.p; p.seg_valid = (const int*)h->seg_valid.p;
     p.seg_len = h->cfg.segment_length; p.normalize = h->cfg.normalize; p.padded = h->padded; p.nf = h->nf;
-    p.basis = h->basis; p.fbfrag = h->fbfrag; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
+    p.basis = h->basis; p.basis_h = h->basis_h; p.fbfrag = h->fbfrag; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
     p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out;
     const char* dbg = getenv("RADAD_DEBUG_LOGMEL");
     p.debug = dbg ? atoi(dbg) : 0;
     h->prof_logmel.begin(st);
-    hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
+    if (h->logmel_f32) hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
+    else hipLaunchKernelGGL(k_logmel_h, dim3((unsigned)n_seg), dim3(LH_THREADS), logmel_h_lds_bytes(), st, p);
     h->prof_logmel.end(st);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
@@ -659,6 +665,8 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
     const int nf = std::min(T, nf_sig);
     RADAD_REQUIRE(nf <= LM_WAVES * 32, "radad_embed_create: %d frames per segment exceed the %d the kernel covers", nf, LM_WAVES * 32);
     RADAD_REQUIRE(padded == L || padded >= L + 2 * N_FFT, "radad_embed_create: padded_samples must be 0 or >= segment_length + 800");
+    RADAD_REQUIRE(FFT_HOP * (nf - 1) + N_FFT - 1 + 8 * ((FFT_HOP * (nf - 1) + N_FFT - 1) / FFT_HOP) + 8 <= LH_SIG_HALFS,
+                  "radad_embed_create: %d frames per segment exceed the LDS planes of k_logmel_h", nf);
     int ndev = 0;
     RADAD_HIP_CHECK(hipGetDeviceCount(&ndev));
     RADAD_REQUIRE(device >= 0 && device < ndev, "radad_embed_create: device %d not in [0,%d)", device, ndev);
@@ -687,6 +695,29 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
                     const size_t base = ((((size_t)bt * NKK + kk) * 2) * 64 + lane) * 4 + j;
                     basis[base] = (float)c;
                     basis[base + 256] = (float)s;
+                }
+    // unfolded, windowed DFT basis x 2^11 as f16 hi/lo planes in MFMA fragment order (k_logmel_h)
+    std::vector<_Float16> basis_h((size_t)LH_NG * 4 * 64 * 8);
+    for (int bt = 0; bt < NBT; ++bt)
+        for (int step = 0; step < LH_STEPS; ++step)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int n = 16 * step + 8 * (lane >> 5) + j;      // 0..399
+                    const int bin = 32 * bt + (lane & 31);
+                    double c = 0.0, sn = 0.0;
+                    if (bin < N_BINS) {
+                        const double w = 0.5 - 0.5 * cos(2.0 * PI * n / N_FFT);   // periodic hann
+                        const int ph = (int)(((int64_t)bin * n) % N_FFT);
+                        c = w * cos(2.0 * PI * ph / N_FFT);
+                        sn = w * sin(2.0 * PI * ph / N_FFT);
+                    }
+                    const float cf = (float)(c * LH_BASIS_SCALE), sf = (float)(sn * LH_BASIS_SCALE);
+                    const _Float16 chi = (_Float16)cf, shi_ = (_Float16)sf;
+                    const size_t base = (((size_t)(bt * LH_STEPS + step) * 4) * 64 + lane) * 8 + j;
+                    basis_h[base] = chi;
+                    basis_h[base + 1 * 512] = (_Float16)(cf - (float)chi);
+                    basis_h[base + 2 * 512] = shi_;
+                    basis_h[base + 3 * 512] = (_Float16)(sf - (float)shi_);
                 }
     // mel filter bank in MFMA A-fragment order
     std::vector<float> fbfrag((size_t)NBT * NMT * 16 * 64, 0.f);
@@ -717,7 +748,9 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
         if (hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { radad_set_error("H2D copy failed"); return RADAD_EHIP; }
         return RADAD_OK;
     };
+    { const char* e = getenv("RADAD_LOGMEL_F32"); h->logmel_f32 = (e && atoi(e) != 0) ? 1 : 0; }
     int rc = put(&h->basis, basis.data(), basis.size() * sizeof(float));
+    if (!rc) rc = put((float**)&h->basis_h, basis_h.data(), basis_h.size() * sizeof(_Float16));
     if (!rc) rc = put(&h->fbfrag, fbfrag.data(), fbfrag.size() * sizeof(float));
     if (!rc) rc = put(&h->wfrag, wfrag.data(), wfrag.size() * sizeof(float));
     if (!rc) rc = put(&h->bias, proj_b_host, (size_t)F * sizeof(float));
@@ -725,6 +758,8 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
     if (!rc) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)logmel_lds_bytes()) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel_h), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)logmel_h_lds_bytes()) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)projpool_lds_bytes(8)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -745,6 +780,7 @@ int radad_embed_destroy(radad_embed_t h) {
     {
         DeviceGuard g(h->device);
         if (h->basis) (void)hipFree(h->basis);
+        if (h->basis_h) (void)hipFree(h->basis_h);
         if (h->fbfrag) (void)hipFree(h->fbfrag);
         if (h->wfrag) (void)hipFree(h->wfrag);
         if (h->bias) (void)hipFree(h->bias);

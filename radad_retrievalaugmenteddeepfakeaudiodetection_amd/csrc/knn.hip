@@ -61,8 +61,6 @@ __device__ __forceinline__ bool better(float s, int i, float ws, int wi) {
 }
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 // One 128 x 128 tile of S = Y . Q^T over the full depth: acc[mt][nt] (wave sub-tile 64 x 64 as 2 x 2 MFMA 32x32 blocks).
 // Global -> LDS staging uses buffer loads: the descriptors are wave-uniform (SGPRs), rows past the end of the
