@@ -77,6 +77,7 @@ struct LogmelParams {
     const float* basis;          // [NBT][NKK][2][64][4]                      (k_logmel: folded fp32 basis)
     const _Float16* basis_h;     // [NBT*25][cos_hi, cos_lo, sin_hi, sin_lo][64][8]  (k_logmel_h: split-f16 basis x 2^11)
     const float* fbfrag;         // [NBT][NMT][16][64]
+    const _Float16* fbfrag_h;    // [NBT][NMT][2 k-halves][hi, lo][64][8]: filter bank x 2^16 in the k order of k_logmel_h
     unsigned nzmask;             // bit (bt*NMT+mt): that (bin tile, mel tile) block of the filter bank is non-zero
     float* logmel;               // [S][nf][80] log10(max(mel,1e-10))  (before the max-8 clamp)
     float* seg_max;              // [S] max over the segment (pre-initialised)
@@ -523,6 +524,7 @@ struct radad_embed_s {
     unsigned nzmask = 0;
     float *basis = nullptr, *fbfrag = nullptr, *wfrag = nullptr, *bias = nullptr;
     _Float16* basis_h = nullptr;
+    _Float16* fbfrag_h = nullptr;
     int logmel_f32 = 0;                  // RADAD_LOGMEL_F32=1: the fp32-MFMA kernel (k_logmel) instead of k_logmel_h
     int* levels_dev = nullptr;
     // plan cache + scratch
@@ -617,7 +619,7 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     LogmelParams p;
     p.wave = wave_dev; p.seg_start = (const int64_t*)h->seg_start.p; p.seg_valid = (const int*)h->seg_valid.p;
     p.seg_len = h->cfg.segment_length; p.normalize = h->cfg.normalize; p.padded = h->padded; p.nf = h->nf;
-    p.basis = h->basis; p.basis_h = h->basis_h; p.fbfrag = h->fbfrag; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
+    p.basis = h->basis; p.basis_h = h->basis_h; p.fbfrag = h->fbfrag; p.fbfrag_h = h->fbfrag_h; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
     p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out;
     const char* dbg = getenv("RADAD_DEBUG_LOGMEL");
     p.debug = dbg ? atoi(dbg) : 0;
@@ -734,6 +736,23 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
                     fbfrag[(((size_t)bt * NMT + mt) * 16 + r) * 64 + lane] = v;
                 }
     h->nzmask = nz;
+    // the same filter bank for k_logmel_h: f16 hi/lo of fb x 2^16, k' = 8 lh + j  <->  bin (j&3) + 16 h + 8 (j>>2) + 4 lh
+    std::vector<_Float16> fbfrag_h((size_t)NBT * NMT * 4 * 64 * 8);
+    for (int bt = 0; bt < NBT; ++bt)
+        for (int mt = 0; mt < NMT; ++mt)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int bin = 32 * bt + (j & 3) + 16 * hh + 8 * (j >> 2) + 4 * (lane >> 5);
+                        const int mel = 32 * mt + (lane & 31);
+                        float v = 0.f;
+                        if (bin < N_BINS && mel < N_MELS) v = mel_filters_host[bin * N_MELS + mel];
+                        const float sc = ldexpf(v, LH_FB_SHIFT);
+                        const _Float16 vh = (_Float16)sc;
+                        const size_t base = ((((size_t)bt * NMT + mt) * 4 + hh * 2) * 64 + lane) * 8 + j;
+                        fbfrag_h[base] = vh;
+                        fbfrag_h[base + 512] = (_Float16)(sc - (float)vh);
+                    }
     const int F = cfg->feat_dim;
     std::vector<float> wfrag((size_t)(F / 32) * 10 * 64 * 4);
     for (int ft = 0; ft < F / 32; ++ft)
@@ -751,6 +770,7 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
     { const char* e = getenv("RADAD_LOGMEL_F32"); h->logmel_f32 = (e && atoi(e) != 0) ? 1 : 0; }
     int rc = put(&h->basis, basis.data(), basis.size() * sizeof(float));
     if (!rc) rc = put((float**)&h->basis_h, basis_h.data(), basis_h.size() * sizeof(_Float16));
+    if (!rc) rc = put((float**)&h->fbfrag_h, fbfrag_h.data(), fbfrag_h.size() * sizeof(_Float16));
     if (!rc) rc = put(&h->fbfrag, fbfrag.data(), fbfrag.size() * sizeof(float));
     if (!rc) rc = put(&h->wfrag, wfrag.data(), wfrag.size() * sizeof(float));
     if (!rc) rc = put(&h->bias, proj_b_host, (size_t)F * sizeof(float));
@@ -781,6 +801,7 @@ int radad_embed_destroy(radad_embed_t h) {
         DeviceGuard g(h->device);
         if (h->basis) (void)hipFree(h->basis);
         if (h->basis_h) (void)hipFree(h->basis_h);
+        if (h->fbfrag_h) (void)hipFree(h->fbfrag_h);
         if (h->fbfrag) (void)hipFree(h->fbfrag);
         if (h->wfrag) (void)hipFree(h->wfrag);
         if (h->bias) (void)hipFree(h->bias);

@@ -797,7 +797,7 @@ constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float2)
 //   identical in both precisions and resolves to the lower id either way).
 // k_merge_lists<KeyT> (radad_topk_merge / _f64): plain P-way merge of final per-shard lists, no rescoring.
 constexpr int KNN_MARGIN = 6;
-constexpr int KW_SAMPLE_ROWS = 4096;   // rows of the threshold pre-pass of the wide kernel (16 one-tile splits)
+constexpr int KW_SAMPLE_SPLITS = 64;    // one-tile splits of the threshold pre-pass of the wide kernel (<= 16384 rows)
 
 struct RefineParams {
     const float* score;       // [nq, n_parts, ksel] fp32 scan scores (larger is better)
@@ -1373,7 +1373,7 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
     const size_t qvec_bytes = (((size_t)nq * sizeof(float)) + 255) & ~(size_t)255;
     const size_t qnorm_bytes = (wide_mode == 0 ? qsplit_bytes + qvec_bytes
                                                : (h->f16 ? ((((size_t)nq * h->dim * 2) + 255) & ~(size_t)255) : 256)) + qvec_bytes;
-    const size_t part_elems = (size_t)nq * std::max(n_splits, wide_mode >= 0 ? KW_SAMPLE_ROWS / KW_M : 0) * (k + margin);   // the sample pre-pass has 16 splits
+    const size_t part_elems = (size_t)nq * std::max(n_splits, wide_mode >= 0 ? KW_SAMPLE_SPLITS : 0) * (k + margin);   // the sample pre-pass has up to 64 splits
     const size_t off_qnorm = (qn_bytes + 255) & ~(size_t)255;
     const size_t off_ps = off_qnorm + qnorm_bytes;
     const size_t off_pi = off_ps + ((part_elems * sizeof(float) + 255) & ~(size_t)255);
@@ -1442,24 +1442,27 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
             else if (wide_mode == 0) hipLaunchKernelGGL((k_knn_wide<32, 0>), g, b, lds, st, kp);
             else hipLaunchKernelGGL((k_knn_wide<32, 1>), g, b, lds, st, kp);
         };
-        // sample pre-pass: the ksel-th best score over the first KW_SAMPLE_ROWS rows is a score at least ksel rows reach,
+        // sample pre-pass: the ksel-th best score over the first rows of the store is a score at least ksel rows reach,
         // so the full scan may start from it instead of -inf (scores of a (row, query) pair do not depend on the tiling).
         // It reuses the head of the partial arrays; the full scan overwrites them afterwards.
-        if (h->ntotal >= 8 * KW_SAMPLE_ROWS && !(p.debug & 16)) {
+        // One tile per workgroup, so up to 64 splits (256 workgroups at 4 query tiles) cost the same as 16: the sample is as
+        // large as one wave of workgroups allows, at most 1/8 of the store.
+        int s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
+        while (s_splits > 8 && (int64_t)s_splits * ksel > 64 * THR_PER_LANE) s_splits -= 8;
+        if (s_splits >= 8 && !(p.debug & 16)) {
             KnnWideParams sp = wp;
-            sp.n = KW_SAMPLE_ROWS; sp.n_splits = KW_SAMPLE_ROWS / KW_M; sp.chunk_rows = KW_M;
+            sp.n = (int64_t)s_splits * KW_M; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
             const dim3 sg((unsigned)(sp.n_qtiles * sp.n_splits));
-            if (wide_mode == 0) {
-                RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_wide_sample<0>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
-                hipLaunchKernelGGL(k_knn_wide_sample<0>, sg, dim3(KW_THREADS), knn_wide_lds_bytes(), st, sp);
-            } else {
-                RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_wide_sample<1>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
-                hipLaunchKernelGGL(k_knn_wide_sample<1>, sg, dim3(KW_THREADS), knn_wide_lds_bytes(), st, sp);
-            }
-            hipLaunchKernelGGL(k_thr_from_parts<32>, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, st, ps, pi, sp.n_splits, ksel, nq,
-                               thr_init);
+            const int svar = (ksel <= 16 ? 0 : 2) + wide_mode;
+            const void* sfn[4] = {reinterpret_cast<const void*>(k_knn_wide_sample<16, 0>), reinterpret_cast<const void*>(k_knn_wide_sample<16, 1>),
+                                  reinterpret_cast<const void*>(k_knn_wide_sample<32, 0>), reinterpret_cast<const void*>(k_knn_wide_sample<32, 1>)};
+            RADAD_HIP_CHECK(hipFuncSetAttribute(sfn[svar], hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
+            const dim3 sb(KW_THREADS);
+            if (svar == 0) hipLaunchKernelGGL((k_knn_wide_sample<16, 0>), sg, sb, knn_wide_lds_bytes(), st, sp);
+            else if (svar == 1) hipLaunchKernelGGL((k_knn_wide_sample<16, 1>), sg, sb, knn_wide_lds_bytes(), st, sp);
+            else if (svar == 2) hipLaunchKernelGGL((k_knn_wide_sample<32, 0>), sg, sb, knn_wide_lds_bytes(), st, sp);
+            else hipLaunchKernelGGL((k_knn_wide_sample<32, 1>), sg, sb, knn_wide_lds_bytes(), st, sp);
+            hipLaunchKernelGGL(k_thr_from_parts, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, ps, pi, sp.n_splits, ksel, nq, thr_init);
             wp.thr_init = thr_init;
         }
         h->prof.begin(st);          // the event pair brackets the full-scan launch only (the kernel the roofline is quoted on)

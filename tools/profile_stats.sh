@@ -1,0 +1,7 @@
+#!/bin/bash
+# rocprofv3 kernel-trace + stats of the default bench (run through gpurun): tools/profile_stats.sh <tag>
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/stats_$1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o p -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 > $OUT.log 2>&1 || exit 1
+ls $OUT
