@@ -272,7 +272,8 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
 // WAVES x 32 features per workgroup: 16 waves (all 512 features of the benchmark: each segment's log-mel is staged once
 // per clip) when F > 256, 8 waves otherwise
 constexpr int PP_FB = 224;           // frames staged per block pass (7 tiles)
-constexpr int PP_LD = N_MELS + 4;    // padded log-mel row in LDS (84 floats: conflict-free b128 frame reads)
+constexpr int PP_LDH = N_MELS + 8;   // padded log-mel row in LDS, in halfs (176 B: conflict-free b128 frame reads)
+constexpr int PP_ACT_SHIFT = 12;     // staged log-mel values ((x+4)/4, |v| <= ~2.5) are split after scaling by 2^12
 
 struct ProjPoolParams {
     const float* logmel;        // [S][nf][80]
@@ -281,7 +282,8 @@ struct ProjPoolParams {
     int nf;                     // frames stored per segment
     int T;                      // frames per segment seen by the pooling (>= nf; frames >= nf are silence)
     int F;
-    const float* wfrag;         // [F/32][10][64][4]
+    const _Float16* wfrag_h;    // [F/32][5 k-steps][hi, lo][64][8]: W x 2^e(feature), split f16, B-fragment order
+    const float* wscale;        // [F] 2^-(e(feature) + PP_ACT_SHIFT): un-scales an accumulator
     const float* bias;          // [F]
     int n_levels;
     int levels[RADAD_MAX_LEVELS];
@@ -295,8 +297,11 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
     constexpr int PP_THREADS = PP_WAVES * 64;
     constexpr int PP_FEATS = PP_WAVES * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* slm = reinterpret_cast<float*>(smem);             // [PP_FB][PP_LD]
-    float* spool = slm + PP_FB * PP_LD;                      // [nbins][PP_FEATS]  current segment
+    // the frame projection runs on the f16 matrix pipe in split form (see knn_wide.inc): the staged log-mel frames are two
+    // f16 planes (hi, lo of v 2^12), W comes pre-split per feature with a power-of-two column scale
+    _Float16* slm_h = reinterpret_cast<_Float16*>(smem);     // [PP_FB][PP_LDH]
+    _Float16* slm_l = slm_h + PP_FB * PP_LDH;                // [PP_FB][PP_LDH]
+    float* spool = reinterpret_cast<float*>(slm_l + PP_FB * PP_LDH);   // [nbins][PP_FEATS]  current segment
     float* sclip = spool + MAX_BINS_TOTAL * PP_FEATS;        // [nbins][PP_FEATS]  running sum over segments
 
     const int tid = threadIdx.x;
@@ -314,11 +319,14 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
     int nbins = 0;
     for (int l = 0; l < p.n_levels; ++l) nbins += p.levels[l];
 
-    // W fragments: lane holds W[8kk + 4lh + j][feat], kk = 0..9 (K = 80)
-    f32x4 wf[10];
+    // W fragments: lane holds W[16 st + 8 lh + j][feat] (hi and lo), st = 0..4 (K = 80)
+    f16x8 wh[5], wl[5];
 #pragma unroll
-    for (int kk = 0; kk < 10; ++kk)
-        wf[kk] = *reinterpret_cast<const f32x4*>(p.wfrag + (((int64_t)ft * 10 + kk) * 64 + lane) * 4);
+    for (int st = 0; st < 5; ++st) {
+        wh[st] = *reinterpret_cast<const f16x8*>(p.wfrag_h + ((((int64_t)ft * 5 + st) * 2 + 0) * 64 + lane) * 8);
+        wl[st] = *reinterpret_cast<const f16x8*>(p.wfrag_h + ((((int64_t)ft * 5 + st) * 2 + 1) * 64 + lane) * 8);
+    }
+    const float wsc = p.wscale[feat];
     const float bias = p.bias[feat];
 
     // spool/sclip columns are wave-private (only lanes lh == 0 of the owning wave touch column fl), so no
@@ -344,9 +352,15 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
                 const int tt = f0 + fr;
                 if (fr < fcount && tt < p.nf)
                     v = *reinterpret_cast<const f32x4*>(p.logmel + ((int64_t)s * p.nf + tt) * N_MELS + c4 * 4);
+                f16x4 vh, vl;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (fmaxf(v[e], floor_v) + 4.0f) / 4.0f;
-                *reinterpret_cast<f32x4*>(slm + fr * PP_LD + c4 * 4) = v;
+                for (int e = 0; e < 4; ++e) {
+                    const float sc = ldexpf((fmaxf(v[e], floor_v) + 4.0f) / 4.0f, PP_ACT_SHIFT);
+                    vh[e] = (_Float16)sc;
+                    vl[e] = (_Float16)(sc - (float)vh[e]);
+                }
+                *reinterpret_cast<f16x4*>(slm_h + fr * PP_LDH + c4 * 4) = vh;
+                *reinterpret_cast<f16x4*>(slm_l + fr * PP_LDH + c4 * 4) = vl;
             }
             __syncthreads();
             const int ntile = (fcount + 31) / 32;
@@ -354,14 +368,17 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                const float* arow = slm + (tile * 32 + l31) * PP_LD + 4 * lh;
+                const int aoff = (tile * 32 + l31) * PP_LDH + 8 * lh;
 #pragma unroll
-                for (int kk = 0; kk < 10; ++kk) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(arow + kk * 8);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wf[kk][j], acc, 0, 0, 0);
+                for (int st = 0; st < 5; ++st) {
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(slm_h + aoff + st * 16);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(slm_l + aoff + st * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[st], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[st], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[st], acc, 0, 0, 0);
                 }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = fmaf(acc[r], wsc, bias);     // exact power-of-two un-scale, then the bias
                 // acc[r] = feature `feat` of frame tfirst + (r&3) + 8(r>>2) + 4lh
                 const int tfirst = f0 + tile * 32;
                 if (!active) continue;
@@ -369,7 +386,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int tt = tfirst + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (tt < p.T) p.frames_out[((int64_t)s * p.T + tt) * p.F + feat] = acc[r] + bias;
+                        if (tt < p.T) p.frames_out[((int64_t)s * p.T + tt) * p.F + feat] = acc[r];
                     }
                 } else {
                     const int tlast = min(tfirst + 32, p.T);   // exclusive
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
                             if (lo <= tfirst && tfirst + 32 <= hi) {       // whole tile inside the bin (wave-uniform)
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) {
-                                    const float x = acc[r] + bias;
+                                    const float x = acc[r];
                                     if (p.pool_mode == RADAD_POOL_MAX) v = fmaxf(v, x);
                                     else v += x;
                                 }
@@ -393,7 +410,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
                                 for (int r = 0; r < 16; ++r) {
                                     const int tt = tfirst + (r & 3) + 8 * (r >> 2) + 4 * lh;
                                     const bool in = tt >= lo && tt < hi;       // hi <= T
-                                    const float x = acc[r] + bias;
+                                    const float x = acc[r];
                                     if (p.pool_mode == RADAD_POOL_MAX) v = in ? fmaxf(v, x) : v;
                                     else v += in ? x : 0.f;
                                 }
@@ -496,7 +513,9 @@ __global__ __launch_bounds__(256) void k_group_mean(const float* __restrict__ in
 }
 
 constexpr size_t logmel_lds_bytes() { return sizeof(float) * (SIG_FLOATS + 2 * CHUNK_FLOATS + 16); }
-constexpr size_t projpool_lds_bytes(int waves) { return sizeof(float) * (PP_FB * PP_LD + 2 * MAX_BINS_TOTAL * waves * 32); }
+constexpr size_t projpool_lds_bytes(int waves) {
+    return sizeof(_Float16) * 2 * PP_FB * PP_LDH + sizeof(float) * 2 * MAX_BINS_TOTAL * waves * 32;
+}
 
 // growable device buffer
 struct DevBuf {
@@ -522,7 +541,8 @@ struct radad_embed_s {
     int device = 0;
     int nbins = 0, T = 0, nf = 0, padded = 0;
     unsigned nzmask = 0;
-    float *basis = nullptr, *fbfrag = nullptr, *wfrag = nullptr, *bias = nullptr;
+    float *basis = nullptr, *fbfrag = nullptr, *wscale = nullptr, *bias = nullptr;
+    _Float16* wfrag_h = nullptr;
     _Float16* basis_h = nullptr;
     _Float16* fbfrag_h = nullptr;
     int logmel_f32 = 0;                  // RADAD_LOGMEL_F32=1: the fp32-MFMA kernel (k_logmel) instead of k_logmel_h
@@ -633,7 +653,7 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
 
 static void fill_projpool(radad_embed_t h, ProjPoolParams& p) {
     p.logmel = (const float*)h->logmel.p; p.seg_max = (const float*)h->seg_max.p; p.clip_seg = (const int64_t*)h->clip_seg.p;
-    p.nf = h->nf; p.T = h->T; p.F = h->cfg.feat_dim; p.wfrag = h->wfrag; p.bias = h->bias; p.n_levels = h->cfg.n_levels;
+    p.nf = h->nf; p.T = h->T; p.F = h->cfg.feat_dim; p.wfrag_h = h->wfrag_h; p.wscale = h->wscale; p.bias = h->bias; p.n_levels = h->cfg.n_levels;
     for (int i = 0; i < RADAD_MAX_LEVELS; ++i) p.levels[i] = i < h->cfg.n_levels ? h->cfg.levels[i] : 0;
     p.pool_mode = h->cfg.pool_mode; p.out = nullptr; p.frames_out = nullptr;
 }
@@ -754,14 +774,31 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
                         fbfrag_h[base + 512] = (_Float16)(sc - (float)vh);
                     }
     const int F = cfg->feat_dim;
-    std::vector<float> wfrag((size_t)(F / 32) * 10 * 64 * 4);
-    for (int ft = 0; ft < F / 32; ++ft)
-        for (int kk = 0; kk < 10; ++kk)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int j = 0; j < 4; ++j) {
-                    const int kidx = 8 * kk + 4 * (lane >> 5) + j;
-                    wfrag[(((size_t)ft * 10 + kk) * 64 + lane) * 4 + j] = proj_w_host[(size_t)kidx * F + ft * 32 + (lane & 31)];
+    // W x 2^e(feature) as f16 hi/lo in B-fragment order; e maps the column maximum into [2^13, 2^14)
+    std::vector<_Float16> wfrag_h((size_t)(F / 32) * 5 * 2 * 64 * 8);
+    std::vector<float> wscale(F);
+    for (int f = 0; f < F; ++f) {
+        float mx = 0.f;
+        for (int k = 0; k < N_MELS; ++k) mx = std::max(mx, fabsf(proj_w_host[(size_t)k * F + f]));
+        int e = 0;
+        if (mx > 0.f && std::isfinite(mx)) {
+            int fe;
+            (void)frexpf(mx, &fe);
+            e = std::max(-100, std::min(100, 14 - fe));
+        }
+        wscale[f] = ldexpf(1.0f, -e - PP_ACT_SHIFT);
+        const int ft = f / 32, l31 = f % 32;
+        for (int st = 0; st < 5; ++st)
+            for (int lhh = 0; lhh < 2; ++lhh)
+                for (int j = 0; j < 8; ++j) {
+                    const int kidx = 16 * st + 8 * lhh + j;
+                    const float sc = ldexpf(proj_w_host[(size_t)kidx * F + f], e);
+                    const _Float16 vh = (_Float16)sc;
+                    const size_t base = ((((size_t)ft * 5 + st) * 2) * 64 + lhh * 32 + l31) * 8 + j;
+                    wfrag_h[base] = vh;
+                    wfrag_h[base + 512] = (_Float16)(sc - (float)vh);
                 }
+    }
     auto put = [&](float** dst, const void* src, size_t bytes) -> int {
         if (hipMalloc((void**)dst, bytes) != hipSuccess) { radad_set_error("hipMalloc failed"); return RADAD_ENOMEM; }
         if (hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { radad_set_error("H2D copy failed"); return RADAD_EHIP; }
@@ -772,7 +809,8 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
     if (!rc) rc = put((float**)&h->basis_h, basis_h.data(), basis_h.size() * sizeof(_Float16));
     if (!rc) rc = put((float**)&h->fbfrag_h, fbfrag_h.data(), fbfrag_h.size() * sizeof(_Float16));
     if (!rc) rc = put(&h->fbfrag, fbfrag.data(), fbfrag.size() * sizeof(float));
-    if (!rc) rc = put(&h->wfrag, wfrag.data(), wfrag.size() * sizeof(float));
+    if (!rc) rc = put((float**)&h->wfrag_h, wfrag_h.data(), wfrag_h.size() * sizeof(_Float16));
+    if (!rc) rc = put(&h->wscale, wscale.data(), wscale.size() * sizeof(float));
     if (!rc) rc = put(&h->bias, proj_b_host, (size_t)F * sizeof(float));
     if (!rc) rc = put((float**)&h->levels_dev, cfg->levels, sizeof(int32_t) * RADAD_MAX_LEVELS);
     if (!rc) {
@@ -803,7 +841,8 @@ int radad_embed_destroy(radad_embed_t h) {
         if (h->basis_h) (void)hipFree(h->basis_h);
         if (h->fbfrag_h) (void)hipFree(h->fbfrag_h);
         if (h->fbfrag) (void)hipFree(h->fbfrag);
-        if (h->wfrag) (void)hipFree(h->wfrag);
+        if (h->wfrag_h) (void)hipFree(h->wfrag_h);
+        if (h->wscale) (void)hipFree(h->wscale);
         if (h->bias) (void)hipFree(h->bias);
         if (h->levels_dev) (void)hipFree(h->levels_dev);
         h->seg_start.release(); h->seg_valid.release(); h->clip_seg.release(); h->logmel.release(); h->seg_max.release();
