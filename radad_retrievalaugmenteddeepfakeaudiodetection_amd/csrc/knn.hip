@@ -1447,7 +1447,9 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
         // It reuses the head of the partial arrays; the full scan overwrites them afterwards.
         // One tile per workgroup, so up to 64 splits (256 workgroups at 4 query tiles) cost the same as 16: the sample is as
         // large as one wave of workgroups allows, at most 1/8 of the store.
+        // ... and no more than one wave of workgroups (256 CUs) in all: with many query tiles the sample shrinks
         int s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
+        s_splits = std::min(s_splits, std::max(8, (256 / n_qtiles) / 8 * 8));
         while (s_splits > 8 && (int64_t)s_splits * ksel > 64 * THR_PER_LANE) s_splits -= 8;
         if (s_splits >= 8 && !(p.debug & 16)) {
             KnnWideParams sp = wp;
