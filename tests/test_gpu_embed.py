@@ -72,6 +72,61 @@ def test_frame_features_protocol(gpu, g_fe):
     assert fe.extract_features([]) == []
 
 
+@pytest.mark.parametrize("gain", [1e-6, 1.0, 3e4])
+def test_logmel_split_scales(gpu, g_fe, gain):
+    """k_logmel_h carries every fp32 sample as two f16 numbers under a per-segment power-of-two scale: amplitudes from 1e-6 to
+    int16-range, an all-zero segment and a segment with one huge spike keep the 1e-4 bar (log10 moves by log10(gain^2))."""
+    fe, _ = _fe(gpu, feature_dim=32, tpp_levels=[1], melproj_normalize=False)
+    seg = (g_fe["segments"][0] * np.float32(gain)).astype(np.float32)
+    spike = seg.copy()
+    spike[12345] = np.float32(500.0 * gain)                       # dominates the scale: the rest lives in the lo halves
+    zero = np.zeros_like(seg)
+    lm = fe.log_mel([seg, spike, zero]).cpu().numpy()
+    np.testing.assert_allclose(lm[0], O.log_mel(seg), rtol=0, atol=1e-4)
+    # frames the spike's window does not reach are unchanged apart from the segment-wide max - 8 clamp
+    far = np.ones(200, bool)
+    far[12345 // 160 - 2: 12345 // 160 + 4] = False
+    ref_spike = O.log_mel(spike)
+    np.testing.assert_allclose(lm[1][~far], ref_spike[~far], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(lm[1][far], ref_spike[far], rtol=0, atol=2e-3)   # 1e-4 relative to the spike's 5 decades
+    np.testing.assert_allclose(lm[2], O.log_mel(zero), rtol=0, atol=1e-6)
+
+
+def test_projection_column_scales(gpu, g_fe, tmp_path):
+    """k_proj_pool splits W per feature column: columns of very different magnitude (and a zero column) keep 1e-4 relative to
+    their own scale"""
+    import torch
+    F = 64
+    w = synth.rows(0, 80, F, 41) * np.exp2((np.arange(F) % 21) - 10).astype(np.float32)[None, :]
+    w[:, 5] = 0
+    b = synth.rows(0, 1, F, 42)[0]
+    path = str(tmp_path / "w.npz")
+    np.savez(path, w=w, b=b)
+    fe, _ = _fe(gpu, feature_dim=F, tpp_levels=[1], melproj_weights_path=path)
+    feats = fe.extract_features([g_fe["segments"][0]])[0].cpu().numpy()
+    x = O.zero_mean_unit_var(g_fe["segments"][0])
+    ref = O.frame_projection(O.log_mel(x), w, b)
+    scale = np.abs(w).max(axis=0) + 1e-30
+    np.testing.assert_allclose((feats - b) / scale, (ref - b) / scale, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(feats[:, 5], b[5], rtol=0, atol=0)
+
+
+def test_fp32_kernels_behind_env_flags(gpu, monkeypatch):
+    """RADAD_LOGMEL_F32=1 selects the fp32-MFMA log-mel kernel; both builds of the front-end agree to the parity bar"""
+    import torch
+    wav = synth.audio(0, 4, 64000, 77)
+    offs = np.arange(5) * 64000
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("RADAD_LOGMEL_F32", flag)
+        fe, _ = _fe(gpu, feature_dim=128, tpp_levels=[1, 2])
+        out.append(fe.embed_clips(torch.from_numpy(wav.reshape(-1)).to(gpu), offs).cpu().numpy())
+    np.testing.assert_allclose(out[0], out[1], rtol=0, atol=5e-5)
+    ref = O.embed_clips(list(wav), 32000, 16000, fe.proj_w, fe.proj_b, (1, 2), "max")
+    np.testing.assert_allclose(out[0], ref, rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out[1], ref, rtol=0, atol=1e-4)
+
+
 def test_tpp_matches_reference_golden(gpu, golden_dir):
     import torch
     import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
