@@ -1716,6 +1716,7 @@ int snap_load_range(radad_knn_t h, const char* path, int64_t row0, int64_t n_row
     DeviceGuard g(h->device);
     RADAD_HIP_CHECK(hipDeviceSynchronize());
     h->ntotal = 0;
+    h->split_rows = 0;                     // the split-f16 copy describes the old contents
     if ((rc = knn_grow(h, n_rows))) return rc;
     const unsigned char* src = map.base + hd.payload_off + (size_t)row0 * rb;
     const size_t total = (size_t)n_rows * rb;

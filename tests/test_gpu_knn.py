@@ -422,3 +422,24 @@ def test_snapshot_loaded_as_row_shards(gpu, tmp_path, store_f16):
         f.truncate(os.path.getsize(path) - 4)
     with pytest.raises(OSError, match="truncated"):
         again.load(path)
+
+
+def test_load_into_used_store_refreshes_split_copy(gpu, tmp_path):
+    """load() replaces the rows of a store that has already scanned a large batch (its split-f16 copy exists and the
+    capacity suffices, so nothing is reallocated): the copy must follow the new rows."""
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    n, nq, dim, k = 6000, 300, 128, 10
+    a_rows, b_rows = synth.rows(0, n, dim, 3101), synth.rows(0, n, dim, 3102)
+    q = synth.rows(0, nq, dim, 3103)
+    src = HipFlatIndex(dim, _lib.METRIC_IP, 0, 0)
+    src.add(b_rows)
+    path = str(tmp_path / "b.radad")
+    src.save(path)
+    idx = HipFlatIndex(dim, _lib.METRIC_IP, 0, 0)
+    idx.add(a_rows)
+    Da, Ia = idx.search(q, k)                               # builds the split copy of A
+    np.testing.assert_array_equal(Ia, O.knn(a_rows, q, k, "IP")[1])
+    idx.load(path)                                          # same size, same capacity: rows replaced in place
+    Db, Ib = idx.search(q, k)
+    np.testing.assert_array_equal(Ib, O.knn(b_rows, q, k, "IP")[1])
+    assert idx.last_launch()["block_threads"] == 512
