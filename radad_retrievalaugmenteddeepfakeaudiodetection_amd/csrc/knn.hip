@@ -1451,7 +1451,8 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
         int s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
         s_splits = std::min(s_splits, std::max(8, (256 / n_qtiles) / 8 * 8));
         while (s_splits > 8 && (int64_t)s_splits * ksel > 64 * THR_PER_LANE) s_splits -= 8;
-        if (s_splits >= 8 && !(p.debug & 16)) {
+        // ... and it only pays when a workgroup of the full scan has several tiles to filter (it costs one tile's latency)
+        if (s_splits >= 8 && chunk_rows >= 8 * KW_M && !(p.debug & 16)) {
             KnnWideParams sp = wp;
             sp.n = (int64_t)s_splits * KW_M; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
             const dim3 sg((unsigned)(sp.n_qtiles * sp.n_splits));
