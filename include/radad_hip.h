@@ -118,6 +118,10 @@ int radad_knn_snapshot_info(const char* path, int* dim_out, int* metric_out, int
 /* seconds spent in the most recent search's kernels are NOT measured here; use HIP events on `stream`.
  * Query the launch geometry of the last search (for roofline accounting in bench.py). */
 int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, int* block_threads);
+/* k > 10 with more than 128 queries: the scan keeps 16 candidates per store chunk and the re-rank certifies per query
+ * that no chunk's list was exhausted; queries that fail are searched again with full-length lists (same results as if
+ * the whole batch had been).  Number of such queries in the most recent search (diagnostics). */
+int radad_knn_last_recheck(radad_knn_t h, int* n_queries);
 
 /* HIP-event timing of the scan kernel (k_knn_f32) alone, on the stream each search is enqueued on:
  * enable -> every search records an event pair around the kernel launch (ring of 64); read synchronises on the

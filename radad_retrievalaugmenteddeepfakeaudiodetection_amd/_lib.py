@@ -68,6 +68,7 @@ SIGNATURES = {
     "radad_knn_load_range": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64]),
     "radad_knn_snapshot_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                           C.POINTER(C.c_int64)]),
+    "radad_knn_last_recheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_last_launch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "radad_knn_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "radad_knn_profile_read": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.POINTER(C.c_int)]),

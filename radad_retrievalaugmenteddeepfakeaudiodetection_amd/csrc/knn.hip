@@ -800,9 +800,12 @@ constexpr int KNN_MARGIN = 6;
 constexpr int KW_SAMPLE_SPLITS = 64;    // one-tile splits of the threshold pre-pass of the wide kernel (<= 16384 rows)
 
 struct RefineParams {
-    const float* score;       // [nq, n_parts, ksel] fp32 scan scores (larger is better)
-    const int* idx;           // [nq, n_parts, ksel] local row or IDX_SENTINEL
+    const float* score;       // [nq, n_parts, part_len] fp32 scan scores (larger is better), each list sorted
+    const int* idx;           // [nq, n_parts, part_len] local row or IDX_SENTINEL
     int n_parts, ksel, k, dim, l2;
+    int part_len;             // entries per partial list; < ksel when the scan kept truncated lists (see `flags`)
+    int* flags;               // optional [nq]: 1 when a truncated list was used up by the selection (it may hide better rows)
+    int* flag_count;          // optional [1]: number of flagged queries (atomicAdd)
     int64_t nq;
     const void* db;           // stored rows (normalised for cosine); fp16 when db_f16
     int db_f16;
@@ -836,8 +839,8 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
         int bi = IDX_SENTINEL, bp = -1;
         for (int part = lane; part < p.n_parts; part += 64) {
             const int pos = s_pos[part];
-            if (pos >= p.ksel) continue;
-            const int64_t off = ((int64_t)q * p.n_parts + part) * p.ksel + pos;
+            if (pos >= p.part_len) continue;
+            const int64_t off = ((int64_t)q * p.n_parts + part) * p.part_len + pos;
             const int id = p.idx[off];
             if (id == IDX_SENTINEL) continue;
             const float sc = p.score[off];
@@ -854,6 +857,20 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
         if ((bp & 63) == lane) s_pos[bp] += 1;
         if (lane == 0) c_id[nsel] = bi;
         ++nsel;
+    }
+    // Truncated lists (part_len < ksel): a list the selection consumed completely -- and that was full -- may hide rows that
+    // beat the last ones selected; everything else it hides is below its own last entry, hence below every selected one.
+    if (p.flags) {
+        int bad = 0;
+        for (int part = lane; part < p.n_parts; part += 64)
+            if (s_pos[part] >= p.part_len &&
+                p.idx[((int64_t)q * p.n_parts + part) * p.part_len + p.part_len - 1] != IDX_SENTINEL) bad = 1;
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) bad |= __shfl_xor(bad, ofs, 64);
+        if (lane == 0) {
+            p.flags[q] = bad;
+            if (bad) atomicAdd(p.flag_count, 1);
+        }
     }
     // 2) float64 re-score of the survivors
     const float* qrow = p.q + q * p.dim;
@@ -1107,6 +1124,7 @@ struct radad_knn_s {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     int last_qtiles = 0, last_splits = 0, last_threads = KNN_THREADS;
+    int last_recheck = 0;      // queries of the most recent truncated-list search that were searched again (see knn_search_locked)
     EventRing prof;
     std::mutex mu;
 };
@@ -1319,6 +1337,8 @@ int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float
 
 static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k, int margin, float* out_dist_dev,
                            int64_t* out_idx_dev, double* out_key_dev, void* stream);
+static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int k, int margin, float* out_dist_dev,
+                             int64_t* out_idx_dev, double* out_key_dev, void* stream, bool allow_trunc);
 
 int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev, int64_t* out_idx_dev,
                          double* out_key_dev, void* stream) {
@@ -1338,7 +1358,26 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
     RADAD_REQUIRE(q_dev && out_dist_dev && out_idx_dev, "radad_knn_search: NULL buffer");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
+    return knn_search_locked(h, q_dev, nq, k, margin, out_dist_dev, out_idx_dev, out_key_dev, stream, true);
+}
+
+// out[sel[i], :] = src[i, :]   (results of the re-searched queries go back to their rows)
+template <typename T>
+__global__ __launch_bounds__(256) void k_scatter_rows(const T* __restrict__ src, const int64_t* __restrict__ sel, int64_t n, int k,
+                                                      T* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * k) out[sel[i / k] * k + i % k] = src[i];
+}
+
+// the search proper; the caller holds h->mu and has the device selected.
+// allow_trunc: with more than 16 candidates per query wanted (k > 10) the wide kernel still keeps 16-entry lists per store
+// chunk (its 24/32-entry variants spill) and k_merge_refine certifies per query that no chunk's list was used up by the
+// selection; the few queries that fail (>= 17 of their best k+6 rows in one chunk: clustered duplicates) are searched again
+// with full-length lists.  That needs one host synchronisation per call; k <= 10 never takes it.
+static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int k, int margin, float* out_dist_dev,
+                             int64_t* out_idx_dev, double* out_key_dev, void* stream, bool allow_trunc) {
     hipStream_t st = (hipStream_t)stream;
+    if (allow_trunc) h->last_recheck = 0;
 
     int n_qtiles, n_splits;
     int64_t chunk_rows;
@@ -1371,8 +1410,9 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
     // [qh]: fp16 queries (fp16 store) or split-f16 queries + their scales (wide kernel on an fp32 store)
     const size_t qsplit_bytes = (((size_t)nq * h->dim * 4) + 255) & ~(size_t)255;
     const size_t qvec_bytes = (((size_t)nq * sizeof(float)) + 255) & ~(size_t)255;
+    // ... | thr_init [nq] | flags [nq] | flag count
     const size_t qnorm_bytes = (wide_mode == 0 ? qsplit_bytes + qvec_bytes
-                                               : (h->f16 ? ((((size_t)nq * h->dim * 2) + 255) & ~(size_t)255) : 256)) + qvec_bytes;
+                                               : (h->f16 ? ((((size_t)nq * h->dim * 2) + 255) & ~(size_t)255) : 256)) + 2 * qvec_bytes + 256;
     const size_t part_elems = (size_t)nq * std::max(n_splits, wide_mode >= 0 ? KW_SAMPLE_SPLITS : 0) * (k + margin);   // the sample pre-pass has up to 64 splits
     const size_t off_qnorm = (qn_bytes + 255) & ~(size_t)255;
     const size_t off_ps = off_qnorm + qnorm_bytes;
@@ -1399,9 +1439,13 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
     // fp16 store + DMA tile kernel: the scan multiplies fp16 x fp16 (fp32 accumulate), so it gets an fp16 copy of the
     // (normalised) queries; the float64 re-rank below still uses the fp32 queries against the decoded rows.
     const int ksel = k + margin;                 // the scan keeps a few spare candidates for the float64 re-rank
+    const bool trunc = allow_trunc && wide_mode >= 0 && ksel > 16;
+    const int plen = trunc ? 16 : ksel;          // entries of a partial list
     const bool f16_tile = h->f16 && ksel <= 32 && h->dim % 64 == 0;
     float* qscale = (float*)(ws + off_qnorm + qsplit_bytes);
-    float* thr_init = (float*)(ws + off_ps - qvec_bytes);      // last slot of the [qh] region
+    float* thr_init = (float*)(ws + off_ps - 256 - 2 * qvec_bytes);
+    int* flags = (int*)(ws + off_ps - 256 - qvec_bytes);
+    int* flag_count = (int*)(ws + off_ps - 256);
     if (wide_mode == 0)
         hipLaunchKernelGGL(k_split_rows, dim3(rgrid), dim3(256), 0, st, q_use, qh, qscale, nq, h->dim);
     else if (f16_tile)
@@ -1421,12 +1465,12 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
         wp.db = wide_mode == 0 ? (const void*)h->split : (const void*)h->rows;
         wp.rscale = wide_mode == 0 ? h->rscale : nullptr;
         wp.ynorm = h->ynorm; wp.q = qh; wp.qscale = wide_mode == 0 ? qscale : nullptr;
-        wp.n = h->ntotal; wp.nq = (int)nq; wp.row_bytes = h->dim * (wide_mode == 0 ? 4 : 2); wp.k = ksel; wp.l2 = p.l2;
+        wp.n = h->ntotal; wp.nq = (int)nq; wp.row_bytes = h->dim * (wide_mode == 0 ? 4 : 2); wp.k = plen; wp.l2 = p.l2;
         wp.n_qtiles = n_qtiles; wp.n_splits = n_splits; wp.chunk_rows = chunk_rows; wp.part_score = ps; wp.part_idx = pi;
         wp.thr_init = nullptr;
         wp.debug = p.debug;
         // <list entries, mode>: k + margin <= 16 / 24 / 32
-        const int kvar = ksel <= 16 ? 0 : (ksel <= 24 ? 1 : 2);
+        const int kvar = plen <= 16 ? 0 : (plen <= 24 ? 1 : 2);
         const void* fns[3][2] = {{reinterpret_cast<const void*>(k_knn_wide<16, 0>), reinterpret_cast<const void*>(k_knn_wide<16, 1>)},
                                  {reinterpret_cast<const void*>(k_knn_wide<24, 0>), reinterpret_cast<const void*>(k_knn_wide<24, 1>)},
                                  {reinterpret_cast<const void*>(k_knn_wide<32, 0>), reinterpret_cast<const void*>(k_knn_wide<32, 1>)}};
@@ -1450,13 +1494,13 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
         // ... and no more than one wave of workgroups (256 CUs) in all: with many query tiles the sample shrinks
         int s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
         s_splits = std::min(s_splits, std::max(8, (256 / n_qtiles) / 8 * 8));
-        while (s_splits > 8 && (int64_t)s_splits * ksel > 64 * THR_PER_LANE) s_splits -= 8;
+        while (s_splits > 8 && (int64_t)s_splits * plen > 64 * THR_PER_LANE) s_splits -= 8;
         // ... and it only pays when a workgroup of the full scan has several tiles to filter (it costs one tile's latency)
         if (s_splits >= 8 && chunk_rows >= 8 * KW_M && !(p.debug & 16)) {
             KnnWideParams sp = wp;
             sp.n = (int64_t)s_splits * KW_M; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
             const dim3 sg((unsigned)(sp.n_qtiles * sp.n_splits));
-            const int svar = (ksel <= 16 ? 0 : 2) + wide_mode;
+            const int svar = (plen <= 16 ? 0 : 2) + wide_mode;
             const void* sfn[4] = {reinterpret_cast<const void*>(k_knn_wide_sample<16, 0>), reinterpret_cast<const void*>(k_knn_wide_sample<16, 1>),
                                   reinterpret_cast<const void*>(k_knn_wide_sample<32, 0>), reinterpret_cast<const void*>(k_knn_wide_sample<32, 1>)};
             RADAD_HIP_CHECK(hipFuncSetAttribute(sfn[svar], hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
@@ -1465,7 +1509,8 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
             else if (svar == 1) hipLaunchKernelGGL((k_knn_wide_sample<16, 1>), sg, sb, knn_wide_lds_bytes(), st, sp);
             else if (svar == 2) hipLaunchKernelGGL((k_knn_wide_sample<32, 0>), sg, sb, knn_wide_lds_bytes(), st, sp);
             else hipLaunchKernelGGL((k_knn_wide_sample<32, 1>), sg, sb, knn_wide_lds_bytes(), st, sp);
-            hipLaunchKernelGGL(k_thr_from_parts, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, ps, pi, sp.n_splits, ksel, nq, thr_init);
+            hipLaunchKernelGGL(k_thr_from_parts, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, ps, pi, sp.n_splits, plen, ksel, nq,
+                               thr_init);
             wp.thr_init = thr_init;
         }
         h->prof.begin(st);          // the event pair brackets the full-scan launch only (the kernel the roofline is quoted on)
@@ -1518,14 +1563,55 @@ static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k,
 
     RefineParams m;
     m.score = ps; m.idx = pi; m.n_parts = n_splits; m.ksel = ksel; m.k = k; m.dim = h->dim; m.l2 = p.l2; m.nq = nq;
+    m.part_len = plen; m.flags = trunc ? flags : nullptr; m.flag_count = trunc ? flag_count : nullptr;
     m.db = h->rows; m.db_f16 = h->f16; m.q = q_use; m.id_map = nullptr; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
     m.out_key = out_key_dev;
+    if (trunc) RADAD_HIP_CHECK(hipMemsetAsync(flag_count, 0, sizeof(int), st));
     const size_t per_wave = (((size_t)ksel * 12 + (size_t)n_splits * 4 + 15) & ~(size_t)15) + 16;
     m.waves_per_block = (int)std::max<size_t>(1, std::min<size_t>(4, (60 * 1024) / per_wave));
     hipLaunchKernelGGL(k_merge_refine, dim3((unsigned)ceil_div64(nq, m.waves_per_block)), dim3(256),
                        per_wave * m.waves_per_block + 64, st, m);
     RADAD_HIP_CHECK(hipGetLastError());
-    return RADAD_OK;
+    if (!trunc) return RADAD_OK;
+
+    // ---- queries whose truncated lists could not be certified: search them again with full-length lists ----------------
+    int n_flag = 0;
+    RADAD_HIP_CHECK(hipMemcpyAsync(&n_flag, flag_count, sizeof(int), hipMemcpyDeviceToHost, st));
+    RADAD_HIP_CHECK(hipStreamSynchronize(st));
+    h->last_recheck = n_flag;
+    if (n_flag == 0) return RADAD_OK;
+    std::vector<int> fl((size_t)nq);
+    RADAD_HIP_CHECK(hipMemcpy(fl.data(), flags, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int64_t> sel;
+    for (int64_t i = 0; i < nq; ++i)
+        if (fl[(size_t)i]) sel.push_back(i);
+    const int64_t nf = (int64_t)sel.size();
+    const size_t b_sel = (((size_t)nf * 8) + 255) & ~(size_t)255, b_q = (((size_t)nf * h->dim * 4) + 255) & ~(size_t)255;
+    const size_t b_d = (((size_t)nf * k * 4) + 255) & ~(size_t)255, b_i = (((size_t)nf * k * 8) + 255) & ~(size_t)255;
+    char* tmp = nullptr;
+    if (hipMalloc(&tmp, b_sel + b_q + b_d + 2 * b_i) != hipSuccess) { radad_set_error("hipMalloc of the re-search buffers failed"); return RADAD_ENOMEM; }
+    int64_t* sel_d = (int64_t*)tmp;
+    float* q_t = (float*)(tmp + b_sel);
+    float* d_t = (float*)(tmp + b_sel + b_q);
+    int64_t* i_t = (int64_t*)(tmp + b_sel + b_q + b_d);
+    double* k_t = (double*)(tmp + b_sel + b_q + b_d + b_i);
+    const int keep_qt = h->last_qtiles, keep_sp = h->last_splits, keep_th = h->last_threads;
+    int rc = RADAD_OK;
+    if (hipMemcpy(sel_d, sel.data(), (size_t)nf * 8, hipMemcpyHostToDevice) != hipSuccess) { radad_set_error("H2D copy failed"); rc = RADAD_EHIP; }
+    if (rc == RADAD_OK) {
+        hipLaunchKernelGGL(k_gather_rows<float>, dim3((unsigned)ceil_div64(nf, 4)), dim3(256), 0, st, q_dev, sel_d, nf, nq, (int64_t)0, h->dim, q_t);
+        rc = knn_search_locked(h, q_t, nf, k, margin, d_t, i_t, out_key_dev ? k_t : nullptr, stream, false);
+    }
+    if (rc == RADAD_OK) {
+        const unsigned sg = (unsigned)ceil_div64(nf * k, 256);
+        hipLaunchKernelGGL(k_scatter_rows<float>, dim3(sg), dim3(256), 0, st, d_t, sel_d, nf, k, out_dist_dev);
+        hipLaunchKernelGGL(k_scatter_rows<int64_t>, dim3(sg), dim3(256), 0, st, i_t, sel_d, nf, k, out_idx_dev);
+        if (out_key_dev) hipLaunchKernelGGL(k_scatter_rows<double>, dim3(sg), dim3(256), 0, st, k_t, sel_d, nf, k, out_key_dev);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { radad_set_error("re-search scatter failed"); rc = RADAD_EHIP; }
+    }
+    (void)hipFree(tmp);
+    h->last_qtiles = keep_qt; h->last_splits = keep_sp; h->last_threads = keep_th;
+    return rc;
 }
 
 extern "C" {
@@ -1612,6 +1698,12 @@ int radad_knn_profile_read(radad_knn_t h, float* ms_out, int cap, int* n_out) {
     int rc = h->prof.read(ms_out, cap, n_out);
     if (rc) radad_set_error("reading profile events failed");
     return rc;
+}
+
+int radad_knn_last_recheck(radad_knn_t h, int* n_queries) {
+    RADAD_REQUIRE(h && n_queries, "NULL argument");
+    *n_queries = h->last_recheck;
+    return RADAD_OK;
 }
 
 int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, int* block_threads) {

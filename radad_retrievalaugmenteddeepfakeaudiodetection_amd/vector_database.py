@@ -169,7 +169,9 @@ class HipFlatIndex:
     def last_launch(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         _lib.check(self._lib.radad_knn_last_launch(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"query_tiles": a.value, "db_splits": b.value, "block_threads": c.value}
+        r = C.c_int()
+        _lib.check(self._lib.radad_knn_last_recheck(self._h, C.byref(r)))
+        return {"query_tiles": a.value, "db_splits": b.value, "block_threads": c.value, "rechecked_queries": r.value}
 
     def profile(self, enable: bool = True):
         """record HIP events around every scan-kernel launch (ring of 64)"""

@@ -443,3 +443,35 @@ def test_load_into_used_store_refreshes_split_copy(gpu, tmp_path):
     Db, Ib = idx.search(q, k)
     np.testing.assert_array_equal(Ib, O.knn(b_rows, q, k, "IP")[1])
     assert idx.last_launch()["block_threads"] == 512
+
+
+@pytest.mark.parametrize("metric", ["L2", "COSINE"])
+def test_knn_truncated_lists_recheck(gpu, metric):
+    """k = 15 with a large batch: the scan keeps 16 candidates per store chunk and the re-rank certifies each query.  Queries
+    whose best rows are clustered in ONE chunk (30 near-duplicates stored contiguously) exhaust that chunk's list and must be
+    searched again with full-length lists; everybody else must not be."""
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    n, nq, dim, k = 60000, 300, 64, 15
+    db = synth.rows(0, n, dim, 4101)
+    q = synth.rows(0, nq, dim, 4102)
+    clustered = [3, 77, 150, 299]
+    bases = [1030, 6000, 11010, 16130]                      # each cluster inside one 256-row chunk of the scan
+    for c, j in enumerate(clustered):                       # 30 consecutive rows around query j
+        base = bases[c]
+        for t in range(30):
+            db[base + t] = q[j] + np.float32(0.02 + 0.001 * t) * synth.rows(base + t, 1, dim, 4103)[0]
+    m = {"L2": _lib.METRIC_L2, "COSINE": _lib.METRIC_COSINE}[metric]
+    idx = HipFlatIndex(dim, m, 0, 0)
+    idx.add(db)
+    D, I = idx.search(q, k)
+    info = idx.last_launch()
+    assert info["block_threads"] == 512
+    assert len(clustered) <= info["rechecked_queries"] <= len(clustered) + 3, info
+    od, oi = O.knn(db, q, k, metric)
+    np.testing.assert_array_equal(I, oi)
+    np.testing.assert_allclose(D, od, rtol=1e-5, atol=1e-5)
+    for c, j in enumerate(clustered):
+        assert set(I[j]) <= set(range(bases[c], bases[c] + 30))
+    # k <= 10 never takes the certified path
+    idx.search(q, 10)
+    assert idx.last_launch()["rechecked_queries"] == 0
