@@ -1382,10 +1382,13 @@ static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int 
     int n_qtiles, n_splits;
     int64_t chunk_rows;
     knn_geometry(std::max<int64_t>(h->ntotal, 1), nq, &n_qtiles, &n_splits, &chunk_rows);
-    // large batches take the wide kernel on the f16 matrix pipe: split-f16 copy of an fp32 store (mode 0) or the fp16
+    // batches of more than 16 queries take the wide kernel on the f16 matrix pipe: split-f16 copy of an fp32 store (mode 0) or the fp16
     // store as it is (mode 1); see knn_wide.inc.  RADAD_KNN_SPLIT=0 keeps an fp32 store on the fp32 tile kernel.
     int wide_mode = -1;
-    if (nq > KT_N && k + margin <= 32 && h->ntotal > 0) {
+    // every batch above the small-batch streaming kernel's 16 queries: measured at 1 M x 512, 32 / 64 / 128 queries take
+    // 0.82 / 0.86 / 0.92 ms per search here against 1.30 / 1.35 / 1.54 ms on the fp32 tile kernel (RADAD_WIDE_MIN_Q moves it)
+    static const int wide_min_q = [] { const char* e = getenv("RADAD_WIDE_MIN_Q"); return e ? atoi(e) : SQ_NQ + 1; }();
+    if (nq >= wide_min_q && k + margin <= 32 && h->ntotal > 0) {
         if (h->f16) { if (h->dim % 64 == 0) wide_mode = 1; }
         else if (knn_ensure_split(h, st)) wide_mode = 0;
     }

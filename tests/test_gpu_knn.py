@@ -58,9 +58,11 @@ def test_knn_matches_oracle(gpu, metric, n, nq, dim, k):
                                         (2500, 9, 96, 30),         # small batch with k too large for the streaming kernel
                                         (5000, 16, 2048, 10),      # streaming kernel at its largest dim
                                         (5000, 3, 4096, 10)])      # small batch, dim beyond the streaming kernel
-def test_knn_kernel_variants(gpu, metric, n, nq, dim, k):
-    """every dispatch branch of radad_knn_search: tile kernel with register lists (16/32), generic tile kernel,
-    streaming small-batch kernel"""
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_knn_kernel_variants(gpu, monkeypatch, split, metric, n, nq, dim, k):
+    """every dispatch branch of radad_knn_search: wide f16-pipe kernel (split on, > 16 queries, dim % 32 == 0), fp32 tile
+    kernel with register lists (16/32; split off), generic tile kernel, streaming small-batch kernel"""
+    monkeypatch.setenv("RADAD_KNN_SPLIT", split)
     db = synth.rows(0, n, dim, 1001)
     q = synth.rows(0, nq, dim, 1002)
     for j in range(nq):
