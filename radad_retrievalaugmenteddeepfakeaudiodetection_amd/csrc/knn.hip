@@ -1497,7 +1497,7 @@ static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int 
         // ... and no more than one wave of workgroups (256 CUs) in all: with many query tiles the sample shrinks
         int s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
         s_splits = std::min(s_splits, std::max(8, (256 / n_qtiles) / 8 * 8));
-        while (s_splits > 8 && (int64_t)s_splits * plen > 64 * THR_PER_LANE) s_splits -= 8;
+        static_assert(KW_SAMPLE_SPLITS <= THR_MAX_PARTS, "k_thr_from_parts gives one lane to each sample split");
         // ... and it only pays when a workgroup of the full scan has several tiles to filter (it costs one tile's latency)
         if (s_splits >= 8 && chunk_rows >= 8 * KW_M && !(p.debug & 16)) {
             KnnWideParams sp = wp;
