@@ -169,6 +169,22 @@ def test_embed_clips_fixed_length(gpu, levels, mode, F):
     np.testing.assert_allclose(emb, ref, rtol=0, atol=1e-4)
 
 
+@pytest.mark.parametrize("seg_s,overlap", [(1.0, 0.5), (0.5, 0.25), (0.03, 0.0), (1.5, 0.5)])
+def test_embed_other_segment_lengths(gpu, seg_s, overlap):
+    """segment lengths other than the reference's 2 s (16000, 8000, 480 and 24000 samples): fewer frame tiles than waves
+    (idle waves leave early), one- and three-tile waves, short clips padded"""
+    import torch
+    fe, _ = _fe(gpu, feature_dim=64, tpp_levels=[1, 2], segment_length=seg_s, segment_overlap=overlap)
+    L, hop = fe.segment_length, fe.hop_length
+    lens = [L // 2, L, 3 * L + 17, 40000]
+    wav = synth.audio(0, len(lens), max(lens), 2235)
+    clips = [wav[i, :n] for i, n in enumerate(lens)]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    emb = fe.embed_clips(torch.from_numpy(np.concatenate(clips)).to(gpu), offs).cpu().numpy()
+    ref = O.embed_clips(clips, L, hop, fe.proj_w, fe.proj_b, (1, 2), "max")
+    np.testing.assert_allclose(emb, ref, rtol=0, atol=1e-4)
+
+
 def test_embed_clips_ragged_lengths(gpu):
     """variable-length clips (config 3): short clip zero-padded, dropped tails, 1..6 segments"""
     import torch
