@@ -1442,7 +1442,8 @@ static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int 
     // fp16 store + DMA tile kernel: the scan multiplies fp16 x fp16 (fp32 accumulate), so it gets an fp16 copy of the
     // (normalised) queries; the float64 re-rank below still uses the fp32 queries against the decoded rows.
     const int ksel = k + margin;                 // the scan keeps a few spare candidates for the float64 re-rank
-    const bool trunc = allow_trunc && wide_mode >= 0 && ksel > 16;
+    // (with fewer than 8 non-empty chunks most queries would exhaust a chunk's list: keep full-length lists there)
+    const bool trunc = allow_trunc && wide_mode >= 0 && ksel > 16 && ceil_div64(h->ntotal, chunk_rows) >= 8;
     const int plen = trunc ? 16 : ksel;          // entries of a partial list
     const bool f16_tile = h->f16 && ksel <= 32 && h->dim % 64 == 0;
     float* qscale = (float*)(ws + off_qnorm + qsplit_bytes);
