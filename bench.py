@@ -39,8 +39,8 @@ PEAK_HBM_GBPS = 8000.0
 # 16-B/lane stream, MI355X_MICROARCH.md "HBM") + WRITE_SIZE 8.2e3 KB x 1024.  Infinity-Cache hits are counted in
 # FETCH_SIZE, so this is an upper bound on DRAM traffic; it is only meaningful for that exact workload.
 SCAN_TRAFFIC_BYTES_R1B = 4.18399e6 * 1024 * 2 + 8195.59 * 1024
-# the same for k_knn_wide (profiles/r1_d_pmc_summary.txt): FETCH_SIZE 1.526e6 KB, WRITE_SIZE 3.93e4 KB per full-scan launch
-SCAN_TRAFFIC_BYTES_WIDE = 1.526e6 * 1024 * 2 + 3.932e4 * 1024
+# the same for k_knn_wide (profiles/r1_d_pmc_summary.txt): FETCH_SIZE 1.587e6 KB, WRITE_SIZE 4.83e4 KB per full-scan launch
+SCAN_TRAFFIC_BYTES_WIDE = 1.587e6 * 1024 * 2 + 4.831e4 * 1024
 
 
 def planted_row(j, c, n_total):
