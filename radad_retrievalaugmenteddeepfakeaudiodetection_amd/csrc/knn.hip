@@ -1416,7 +1416,8 @@ static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int 
     // ... | thr_init [nq] | flags [nq] | flag count
     const size_t qnorm_bytes = (wide_mode == 0 ? qsplit_bytes + qvec_bytes
                                                : (h->f16 ? ((((size_t)nq * h->dim * 2) + 255) & ~(size_t)255) : 256)) + 2 * qvec_bytes + 256;
-    const size_t part_elems = (size_t)nq * std::max(n_splits, wide_mode >= 0 ? KW_SAMPLE_SPLITS : 0) * (k + margin);   // the sample pre-pass has up to 64 splits
+    // (the sample pre-pass writes 16 entries per query for each of its up to 64 tiles into the head of the same arrays)
+    const size_t part_elems = (size_t)nq * std::max<size_t>((size_t)n_splits * (k + margin), wide_mode >= 0 ? (size_t)KW_SAMPLE_SPLITS * 16 : 0);
     const size_t off_qnorm = (qn_bytes + 255) & ~(size_t)255;
     const size_t off_ps = off_qnorm + qnorm_bytes;
     const size_t off_pi = off_ps + ((part_elems * sizeof(float) + 255) & ~(size_t)255);
@@ -1498,22 +1499,19 @@ static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int 
         // ... and no more than one wave of workgroups (256 CUs) in all: with many query tiles the sample shrinks
         int s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
         s_splits = std::min(s_splits, std::max(8, (256 / n_qtiles) / 8 * 8));
-        static_assert(KW_SAMPLE_SPLITS <= THR_MAX_PARTS, "k_thr_from_parts gives one lane to each sample split");
+        static_assert(KW_SAMPLE_SPLITS * 8 <= 64 * THR_LISTS_PER_LANE, "k_thr_from_parts: lists per lane");
         // ... and it only pays when a workgroup of the full scan has several tiles to filter (it costs one tile's latency)
         if (s_splits >= 8 && chunk_rows >= 8 * KW_M && !(p.debug & 16)) {
             KnnWideParams sp = wp;
             sp.n = (int64_t)s_splits * KW_M; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
             const dim3 sg((unsigned)(sp.n_qtiles * sp.n_splits));
-            const int svar = (plen <= 16 ? 0 : 2) + wide_mode;
-            const void* sfn[4] = {reinterpret_cast<const void*>(k_knn_wide_sample<16, 0>), reinterpret_cast<const void*>(k_knn_wide_sample<16, 1>),
-                                  reinterpret_cast<const void*>(k_knn_wide_sample<32, 0>), reinterpret_cast<const void*>(k_knn_wide_sample<32, 1>)};
-            RADAD_HIP_CHECK(hipFuncSetAttribute(sfn[svar], hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
+            sp.k = 16;                                           // 8 holders x 2 entries per query and tile
+            const void* sfn = wide_mode == 0 ? reinterpret_cast<const void*>(k_knn_wide_sample<0>) : reinterpret_cast<const void*>(k_knn_wide_sample<1>);
+            RADAD_HIP_CHECK(hipFuncSetAttribute(sfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
             const dim3 sb(KW_THREADS);
-            if (svar == 0) hipLaunchKernelGGL((k_knn_wide_sample<16, 0>), sg, sb, knn_wide_lds_bytes(), st, sp);
-            else if (svar == 1) hipLaunchKernelGGL((k_knn_wide_sample<16, 1>), sg, sb, knn_wide_lds_bytes(), st, sp);
-            else if (svar == 2) hipLaunchKernelGGL((k_knn_wide_sample<32, 0>), sg, sb, knn_wide_lds_bytes(), st, sp);
-            else hipLaunchKernelGGL((k_knn_wide_sample<32, 1>), sg, sb, knn_wide_lds_bytes(), st, sp);
-            hipLaunchKernelGGL(k_thr_from_parts, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, ps, pi, sp.n_splits, plen, ksel, nq,
+            if (wide_mode == 0) hipLaunchKernelGGL(k_knn_wide_sample<0>, sg, sb, knn_wide_lds_bytes(), st, sp);
+            else hipLaunchKernelGGL(k_knn_wide_sample<1>, sg, sb, knn_wide_lds_bytes(), st, sp);
+            hipLaunchKernelGGL(k_thr_from_parts, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, ps, pi, sp.n_splits * 8, 2, ksel, nq,
                                thr_init);
             wp.thr_init = thr_init;
         }
