@@ -797,6 +797,7 @@ constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float2)
 //   identical in both precisions and resolves to the lower id either way).
 // k_merge_lists<KeyT> (radad_topk_merge / _f64): plain P-way merge of final per-shard lists, no rescoring.
 constexpr int KNN_MARGIN = 6;
+constexpr int KW_SAMPLE_BLOCKS = 1024;   // workgroups of the threshold pre-pass, at most (4 waves of one-tile workgroups)
 constexpr int KW_SAMPLE_SPLITS = 64;    // one-tile splits of the threshold pre-pass of the wide kernel (<= 16384 rows)
 
 struct RefineParams {
@@ -1496,9 +1497,10 @@ static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int 
         // It reuses the head of the partial arrays; the full scan overwrites them afterwards.
         // One tile per workgroup, so up to 64 splits (256 workgroups at 4 query tiles) cost the same as 16: the sample is as
         // large as one wave of workgroups allows, at most 1/8 of the store.
-        // ... and no more than one wave of workgroups (256 CUs) in all: with many query tiles the sample shrinks
+        // ... and no more than KW_SAMPLE_BLOCKS workgroups in all: with many query tiles the sample shrinks (8192 queries x
+        // 125 k rows, the per-rank shape of an 8-GPU run: 256 / 512 / 1024 workgroups -> 3.47 / 3.26 / 3.23 ms per search)
         int s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
-        s_splits = std::min(s_splits, std::max(8, (256 / n_qtiles) / 8 * 8));
+        s_splits = std::min(s_splits, std::max(8, (KW_SAMPLE_BLOCKS / n_qtiles) / 8 * 8));
         static_assert(KW_SAMPLE_SPLITS * 8 <= 64 * THR_LISTS_PER_LANE, "k_thr_from_parts: lists per lane");
         // ... and it only pays when a workgroup of the full scan has several tiles to filter (it costs one tile's latency)
         if (s_splits >= 8 && chunk_rows >= 8 * KW_M && !(p.debug & 16)) {
