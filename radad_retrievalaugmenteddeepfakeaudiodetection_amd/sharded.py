@@ -79,6 +79,27 @@ class ShardedSearch:
             dist.all_gather_into_tensor(out, t, group=self.group)
         return out
 
+    def _exchange(self, t, qr: int):
+        """t [world*qr, k]: this shard's lists for ALL queries, rank-major -> [world, qr, k]: every shard's lists for THIS
+        rank's queries.  One all-to-all (each rank receives only the rows it merges: 1/world of an all-gather's traffic);
+        backends without it fall back to the all-gather and a slice."""
+        import torch
+        import torch.distributed as dist
+        t = t.contiguous()
+        k = t.shape[1]
+        try:
+            if t.is_cuda and dist.get_backend(self.group) == "gloo":
+                host_out = torch.empty((self.world * qr, k), dtype=t.dtype)
+                dist.all_to_all_single(host_out, t.cpu(), group=self.group)
+                return host_out.to(t.device).view(self.world, qr, k)
+            out = torch.empty((self.world * qr, k), device=t.device, dtype=t.dtype)
+            dist.all_to_all_single(out, t, group=self.group)
+            return out.view(self.world, qr, k)
+        except (RuntimeError, NotImplementedError):
+            Q = t.shape[0]
+            sl = slice(self.rank * qr, (self.rank + 1) * qr)
+            return self._all_gather(t).view(self.world, Q, k)[:, sl].contiguous()
+
     def gather_queries(self, q_local):
         return q_local if self.world == 1 else self._all_gather(q_local)
 
@@ -92,11 +113,10 @@ class ShardedSearch:
         if self.world == 1:
             return d_loc.float(), i_loc
         Q = q_all.shape[0]
-        # concatenated output form (accepted by both RCCL and gloo), viewed as [G, Q, k]
-        d_all = self._all_gather(d_loc).view(self.world, Q, k)
-        i_all = self._all_gather(i_loc).view(self.world, Q, k)
         if return_all:
+            # concatenated output form (accepted by both RCCL and gloo), viewed as [G, Q, k]
+            d_all = self._all_gather(d_loc).view(self.world, Q, k)
+            i_all = self._all_gather(i_loc).view(self.world, Q, k)
             return self.merge(self.metric, d_all, i_all, k)
         qr = q_local.shape[0]
-        sl = slice(self.rank * qr, (self.rank + 1) * qr)
-        return self.merge(self.metric, d_all[:, sl].contiguous(), i_all[:, sl].contiguous(), k)
+        return self.merge(self.metric, self._exchange(d_loc, qr), self._exchange(i_loc, qr), k)
