@@ -66,7 +66,7 @@ def main():
                     help="f16 = the reference's use_float16 knob (fp16 rows, fp16 MFMA scan); NOT the headline configuration")
     args = ap.parse_args()
     if args.scan == "f32":
-        os.environ["RADAD_KNN_SPLIT"] = "0"       # read by radad_knn_create
+        os.environ["RADAD_KNN_HI"] = "0"       # read by radad_knn_create
 
     import numpy as np
     import torch
@@ -199,9 +199,9 @@ def main():
     if f16:
         alg_bytes = 2.0 * (hi - lo) * DIM + 2.0 * Q * DIM + 12.0 * Q * TOP_K
     if wide:
-        kname = "k_knn_wide<16,%d>" % (1 if f16 else 0)
+        kname = "k_knn_hi<0>"
         peak = PEAK_MFMA_F16_TFLOPS
-        issued = flops * (1.0 if f16 else 3.0)                # split form: 3 f16 MFMA products per fp32 product
+        issued = flops                                        # one f16 MFMA product per element (certified filter)
         dtype = ("f32 embed; f16 store + f16 MFMA scan (f32 accumulate, f64 re-rank)" if f16 else
                  "f32 (scan products as 3 f16 MFMAs on hi/lo splits of the fp32 values, f32 accumulate; f64 re-rank from the fp32 rows)")
     else:

@@ -98,6 +98,13 @@ int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float
  * on these keys (radad_topk_merge_f64) so that no cross-shard pair is decided by fp32 rounding. */
 int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev,
                          int64_t* out_idx_dev, double* out_key_dev, void* stream);
+/* same with a choice of query type: RADAD_Q_BF16 = bfloat16 queries [nq, dim] (BASELINE config 5: bf16 embeddings,
+ * the reference's autocast knob feature_extractor.py:84,140) -- decoded exactly to fp32 on the device, then the same
+ * path (cosine normalisation in fp32, as vector_database.py:166 does on whatever it is handed). */
+#define RADAD_Q_F32 0
+#define RADAD_Q_BF16 1
+int radad_knn_search_ex(radad_knn_t h, const void* q_dev, int q_dtype, int64_t nq, int k, float* out_dist_dev,
+                        int64_t* out_idx_dev, double* out_key_dev, void* stream);
 /* host-buffer variant (what index.search(np.ndarray, k) does); synchronous */
 int radad_knn_search_host(radad_knn_t h, const float* q_host, int64_t nq, int k, float* out_dist_host,
                           int64_t* out_idx_host);
@@ -215,6 +222,19 @@ int64_t radad_segment_count(int64_t n_samples, int32_t segment_length, int32_t h
  * out_dev [n_clips, output_dim] fp32.  (process_audio_batch, pipeline.py:392-414, minus file loading) */
 int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_host, int64_t n_clips,
                         float* out_dev, void* stream);
+
+/* same with a choice of output type: RADAD_OUT_BF16 emits the clip embeddings as bfloat16 (rounded to nearest even in
+ * the epilogue of the pooling kernel; BASELINE config 5, the reference's reduced-precision knob feature_extractor.py:84,140) */
+#define RADAD_OUT_F32 0
+#define RADAD_OUT_BF16 1
+int radad_embed_forward_ex(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_host, int64_t n_clips,
+                           void* out_dev, int out_dtype, void* stream);
+/* clip offsets resident on the DEVICE (int64 [n_clips + 1]): the segment plan (segmenter.py:25-39: n_seg per clip,
+ * exclusive scan, start / valid samples of every segment) is built by a kernel, nothing synchronises with the host.
+ * n_samples_total (= clip_offsets[n_clips], known to the caller from the wave buffer's size) only bounds the number of
+ * segments for buffer and grid sizes. */
+int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_dev, int64_t n_clips,
+                            int64_t n_samples_total, void* out_dev, int out_dtype, void* stream);
 
 /* same HIP-event timing for the two embedding kernels (k_logmel, k_proj_pool) of radad_embed_forward */
 int radad_embed_profile(radad_embed_t h, int enable);

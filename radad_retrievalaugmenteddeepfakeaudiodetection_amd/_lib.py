@@ -13,6 +13,8 @@ RADAD_OK, RADAD_EINVAL, RADAD_EHIP, RADAD_ENOMEM, RADAD_EIO, RADAD_ESTATE = 0, -
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
 POOL_MAX, POOL_AVG = 0, 1
 STORE_F32, STORE_F16 = 0, 1
+Q_F32, Q_BF16 = 0, 1
+OUT_F32, OUT_BF16 = 0, 1
 MAX_LEVELS = 8
 KNN_MAX_K = 1024
 
@@ -60,6 +62,8 @@ SIGNATURES = {
     "radad_knn_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "radad_knn_search_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p]),
+    "radad_knn_search_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
     "radad_knn_search_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "radad_knn_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "radad_knn_reconstruct_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -100,6 +104,8 @@ SIGNATURES = {
     "radad_embed_num_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_segment_count": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "radad_embed_forward": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "radad_embed_forward_ex": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    "radad_embed_forward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "radad_embed_normalize": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, c_i32p, C.c_int64, C.c_void_p, C.c_void_p]),
     "radad_embed_logmel": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, c_i32p, C.c_int64, C.c_void_p, C.c_void_p]),
     "radad_embed_frame_features": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, c_i32p, C.c_int64, C.c_void_p,

@@ -27,6 +27,14 @@ void radad_set_error(const char* fmt, ...);
         }                                                                                             \
     } while (0)
 
+// Timing-experiment switches inside kernels (skip a phase and measure the rest): compiled out unless the library is built
+// with -DRADAD_DEBUG_HOOKS, so that no environment variable can make the shipped kernels skip work.
+#ifdef RADAD_DEBUG_HOOKS
+#define RADAD_DBG(flags, bit) ((flags) & (bit))
+#else
+#define RADAD_DBG(flags, bit) 0
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

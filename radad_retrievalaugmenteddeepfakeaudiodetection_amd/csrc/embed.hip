@@ -82,6 +82,7 @@ struct LogmelParams {
     float* logmel;               // [S][nf][80] log10(max(mel,1e-10))  (before the max-8 clamp)
     float* seg_max;              // [S] max over the segment (pre-initialised)
     float* norm_out;             // optional [S][L]: the normalised segment (stage parity); nullptr otherwise
+    const int* n_seg_dev;        // optional: segments of the device-built plan (the grid is an upper bound; blocks beyond leave)
     int debug;                   // timing experiments only (RADAD_DEBUG_LOGMEL): 1 = skip the MFMA loop, 2 = skip the prologue
 };
 
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
     const int l31 = lane & 31;
     const int lh = lane >> 5;
     const int s = blockIdx.x;
+    if (p.n_seg_dev && s >= *p.n_seg_dev) return;       // device-built plan: the grid is an upper bound on the segments
     const int L = p.seg_len;
     const float* src = p.wave + p.seg_start[s];
     const int valid = p.seg_valid[s];
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
             const int i4 = u * LM_THREADS + tid;
             const int i = i4 * 4;
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
-            if (i4 < nv && !(p.debug & 2)) {
+            if (i4 < nv && !RADAD_DBG(p.debug, 2)) {
                 if (vec_ok && i + 4 <= valid) t = *reinterpret_cast<const f32x4*>(src + i);
                 else {
 #pragma unroll
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
         for (int r = 0; r < 16; ++r) zacc[m][r] = 0.f;
 
     int step = 0;   // global chunk counter (bt*NCH + ch)
-    for (int bt = 0; bt < ((p.debug & 1) ? 0 : NBT); ++bt) {
+    for (int bt = 0; bt < (RADAD_DBG(p.debug, 1) ? 0 : NBT); ++bt) {
         f32x16 re, im;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { re[r] = 0.f; im[r] = 0.f; }
@@ -289,8 +291,15 @@ struct ProjPoolParams {
     int levels[RADAD_MAX_LEVELS];
     int pool_mode;
     float* out;                 // [B][nbins*F]      (pooled + segment mean)
+    unsigned short* out_bf16;   // same, emitted as bfloat16 (round to nearest even) instead of `out` when non-null
     float* frames_out;          // optional [S][T][F]: per-frame features (extract_features protocol); no pooling
+    const int* n_groups_dev;    // optional: number of valid groups (device-built plan: the grid is an upper bound)
 };
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float v) {      // plain cast: v_cvt_pk_bf16_f32, NaN stays NaN
+    const __bf16 b = (__bf16)v;
+    return __builtin_bit_cast(unsigned short, b);
+}
 
 template <bool FRAMES_OUT, int PP_WAVES>
 __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjPoolParams p) {
@@ -310,6 +319,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
     const int l31 = lane & 31;
     const int lh = lane >> 5;
     const int clip = blockIdx.x;
+    if (p.n_groups_dev && clip >= *p.n_groups_dev) return;   // (uniform per workgroup: nobody is left at a barrier)
     const int fblk = blockIdx.y;                             // 256-feature block
     const bool active = (fblk * PP_WAVES + wave) * 32 < p.F; // waves past F only keep the barriers company
     const int ft = active ? fblk * PP_WAVES + wave : 0;      // this wave's 32-feature tile
@@ -334,7 +344,8 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
     if (!FRAMES_OUT && lh == 0)
         for (int b = 0; b < nbins; ++b) sclip[b * PP_FEATS + fl] = 0.f;
 
-    const int64_t s_begin = p.clip_seg[clip], s_end = p.clip_seg[clip + 1];
+    // clip_seg == nullptr: one group per segment (ragged batches are pooled per segment and averaged afterwards)
+    const int64_t s_begin = p.clip_seg ? p.clip_seg[clip] : clip, s_end = p.clip_seg ? p.clip_seg[clip + 1] : clip + 1;
     for (int64_t s = s_begin; s < s_end; ++s) {
         const float smax = p.seg_max[s];
         const float floor_v = smax - 8.0f;
@@ -447,8 +458,12 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
     }
     if (!FRAMES_OUT && lh == 0 && active) {
         const float nseg = (float)(s_end - s_begin);
-        for (int b = 0; b < nbins; ++b)
-            p.out[(int64_t)clip * nbins * p.F + (int64_t)b * p.F + feat] = sclip[b * PP_FEATS + fl] / nseg;
+        for (int b = 0; b < nbins; ++b) {
+            const float v = sclip[b * PP_FEATS + fl] / nseg;
+            const int64_t o = (int64_t)clip * nbins * p.F + (int64_t)b * p.F + feat;
+            if (p.out_bf16) p.out_bf16[o] = f32_to_bf16_rne(v);
+            else p.out[o] = v;
+        }
     }
 }
 
@@ -502,14 +517,72 @@ __global__ __launch_bounds__(256) void k_tpp(const float* __restrict__ feats, co
 }
 
 __global__ __launch_bounds__(256) void k_group_mean(const float* __restrict__ in, const int64_t* __restrict__ goff, int dim,
-                                                    float* __restrict__ out) {
+                                                    float* __restrict__ out, unsigned short* __restrict__ out_bf16) {
     const int g = blockIdx.x;
     const int c = blockIdx.y * 256 + threadIdx.x;
     if (c >= dim) return;
     const int64_t a = goff[g], b = goff[g + 1];
     float v = 0.f;
     for (int64_t r = a; r < b; ++r) v += in[r * dim + c];
-    out[(int64_t)g * dim + c] = v / (float)(b - a);
+    v = v / (float)(b - a);
+    if (out_bf16) out_bf16[(int64_t)g * dim + c] = f32_to_bf16_rne(v);
+    else out[(int64_t)g * dim + c] = v;
+}
+
+// ---- the segment plan on the device (segmenter.py:25-39) --------------------------------------------------------------
+// clip b = samples [off[b], off[b+1]);  n_seg = max(1, (N - L) // hop + 1) (Python floor division);  segment i starts at
+// off[b] + i hop and holds min(L, N - i hop) real samples (zero padded to L only when N < L; the tail past the last full
+// window is dropped).  One workgroup: chunks of 1024 clips, an exclusive scan of n_seg with a running carry, then every
+// thread writes its own clip's segments.  Outputs: clip_seg [B+1], seg_start [S], seg_valid [S], n_seg_out[0] = S.
+// Nothing here needs the host: a batch with fresh offsets costs one tiny launch, no synchronisation.
+__global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__ off, int64_t n_clips, int L, int hop,
+                                                     int64_t seg_cap, int64_t* __restrict__ clip_seg, int64_t* __restrict__ seg_start,
+                                                     int* __restrict__ seg_valid, int* __restrict__ n_seg_out) {
+    __shared__ long long s_wave[16];
+    __shared__ long long s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < n_clips; b0 += 1024) {
+        const int64_t b = b0 + tid;
+        long long n = 0, ns = 0;
+        if (b < n_clips) {
+            n = off[b + 1] - off[b];
+            if (n < 0) n = 0;
+            const long long d = n - L;
+            long long q = d / hop;
+            if ((d % hop != 0) && (d < 0)) --q;          // floor division
+            ns = q + 1 > 1 ? q + 1 : 1;
+        }
+        long long inc = ns;                              // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long t = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        long long base = s_carry;
+        for (int w = 0; w < wave; ++w) base += s_wave[w];
+        const long long first = base + inc - ns;         // exclusive prefix of this clip
+        if (b < n_clips) {
+            clip_seg[b] = first;
+            for (long long i = 0; i < ns; ++i) {
+                if (first + i < seg_cap) {
+                    seg_start[first + i] = off[b] + i * hop;
+                    const long long v = n - i * hop;
+                    seg_valid[first + i] = (int)(v < 0 ? 0 : (v > L ? L : v));
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) s_carry = base + inc;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        clip_seg[n_clips] = s_carry;
+        n_seg_out[0] = (int)(s_carry < seg_cap ? s_carry : seg_cap);
+    }
 }
 
 constexpr size_t logmel_lds_bytes() { return sizeof(float) * (SIG_FLOATS + 2 * CHUNK_FLOATS + 16); }
@@ -551,7 +624,13 @@ struct radad_embed_s {
     std::vector<int64_t> plan_key;       // the clip_offsets the cached plan was built from
     int64_t plan_nseg = 0;
     bool plan_uniform = true;            // every clip of the cached plan has the same number of segments
-    DevBuf seg_start, seg_valid, clip_seg, seg_ident, seg_pool, logmel, seg_max, misc;
+    DevBuf seg_start, seg_valid, clip_seg, seg_pool, logmel, seg_max, misc, clip_off, n_seg_dev;
+    bool plan_on_device = false;         // the cached plan came from device-resident offsets: segment count only known there
+    // two pinned staging buffers for clip offsets handed over in host memory (no stream synchronisation on the way)
+    int64_t* pin[2] = {nullptr, nullptr};
+    size_t pin_cap[2] = {0, 0};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    int pin_next = 0;
     EventRing prof_logmel, prof_pool;
     std::mutex mu;
 };
@@ -572,43 +651,59 @@ static int upload(DevBuf& b, const void* host, size_t bytes, hipStream_t st) {
     return RADAD_OK;
 }
 
-// Build the (clip, segment) -> sample range plan (segmenter.py:25-39) and upload it.
+// Launch k_build_plan over device-resident offsets.  seg_cap bounds the number of segments (buffers and grids).
+static int plan_on_device(radad_embed_t h, const int64_t* clip_off_dev, int64_t n_clips, int64_t seg_cap, hipStream_t st) {
+    int rc;
+    if ((rc = h->seg_start.ensure((size_t)seg_cap * sizeof(int64_t)))) return rc;
+    if ((rc = h->seg_valid.ensure((size_t)seg_cap * sizeof(int32_t)))) return rc;
+    if ((rc = h->clip_seg.ensure((size_t)(n_clips + 1) * sizeof(int64_t)))) return rc;
+    if ((rc = h->n_seg_dev.ensure(sizeof(int)))) return rc;
+    hipLaunchKernelGGL(k_build_plan, dim3(1), dim3(1024), 0, st, clip_off_dev, n_clips, h->cfg.segment_length, h->cfg.hop_length,
+                       seg_cap, (int64_t*)h->clip_seg.p, (int64_t*)h->seg_start.p, (int*)h->seg_valid.p, (int*)h->n_seg_dev.p);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+// Plan for clip offsets in HOST memory (segmenter.py:25-39): the host only counts the segments (it needs the grid size);
+// the offsets travel through a pinned staging buffer and the plan itself is built by k_build_plan -- no stream
+// synchronisation, no pageable copies.  The plan of the previous call is reused when the offsets are the same.
 static int build_plan(radad_embed_t h, const int64_t* clip_offsets, int64_t n_clips, hipStream_t st) {
-    if ((int64_t)h->plan_key.size() == n_clips + 1 && memcmp(h->plan_key.data(), clip_offsets, sizeof(int64_t) * (n_clips + 1)) == 0)
+    if (!h->plan_on_device && (int64_t)h->plan_key.size() == n_clips + 1 &&
+        memcmp(h->plan_key.data(), clip_offsets, sizeof(int64_t) * (n_clips + 1)) == 0)
         return RADAD_OK;
-    std::vector<int64_t> seg_start, clip_seg(n_clips + 1, 0);
-    std::vector<int32_t> seg_valid;
     const int L = h->cfg.segment_length, hop = h->cfg.hop_length;
+    int64_t n_seg = 0, first = -1;
+    bool uniform = true;
     for (int64_t b = 0; b < n_clips; ++b) {
         const int64_t n = clip_offsets[b + 1] - clip_offsets[b];
         RADAD_REQUIRE(n >= 0, "radad_embed_forward: clip_offsets must be non-decreasing");
         const int64_t ns = radad_segment_count(n, L, hop);
-        for (int64_t i = 0; i < ns; ++i) {
-            const int64_t start = i * hop;
-            seg_start.push_back(clip_offsets[b] + start);
-            seg_valid.push_back((int32_t)std::max<int64_t>(0, std::min<int64_t>(L, n - start)));
-        }
-        clip_seg[b + 1] = clip_seg[b] + ns;
+        if (first < 0) first = ns;
+        uniform = uniform && ns == first;
+        n_seg += ns;
     }
-    RADAD_HIP_CHECK(hipStreamSynchronize(st));   // pageable host vectors below go out of scope after the copies
+    RADAD_REQUIRE(n_seg < (1ll << 31), "radad_embed_forward: too many segments in one batch");
+    const int slot = h->pin_next;
+    const size_t need = (size_t)(n_clips + 1) * sizeof(int64_t);
+    if (!h->pin_ev[slot]) RADAD_HIP_CHECK(hipEventCreateWithFlags(&h->pin_ev[slot], hipEventDisableTiming));
+    else RADAD_HIP_CHECK(hipEventSynchronize(h->pin_ev[slot]));       // the copy that last used this buffer (two calls ago) is done
+    if (h->pin_cap[slot] < need) {
+        if (h->pin[slot]) (void)hipHostFree(h->pin[slot]);
+        h->pin[slot] = nullptr; h->pin_cap[slot] = 0;
+        RADAD_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->pin[slot]), need + need / 2, hipHostMallocDefault));
+        h->pin_cap[slot] = need + need / 2;
+    }
+    memcpy(h->pin[slot], clip_offsets, need);
     int rc;
-    if ((rc = upload(h->seg_start, seg_start.data(), seg_start.size() * sizeof(int64_t), st))) return rc;
-    if ((rc = upload(h->seg_valid, seg_valid.data(), seg_valid.size() * sizeof(int32_t), st))) return rc;
-    if ((rc = upload(h->clip_seg, clip_seg.data(), clip_seg.size() * sizeof(int64_t), st))) return rc;
-    RADAD_HIP_CHECK(hipStreamSynchronize(st));
-    // ragged batches are pooled per SEGMENT (balanced grid) and averaged afterwards: that path needs the identity
-    // ranges [s, s+1) as its "clip" table
-    bool uniform = true;
-    for (int64_t b = 1; b < n_clips; ++b) uniform = uniform && (clip_seg[b + 1] - clip_seg[b] == clip_seg[1] - clip_seg[0]);
-    if (!uniform) {
-        std::vector<int64_t> ident(seg_start.size() + 1);
-        for (size_t i = 0; i < ident.size(); ++i) ident[i] = (int64_t)i;
-        if ((rc = upload(h->seg_ident, ident.data(), ident.size() * sizeof(int64_t), st))) return rc;
-        RADAD_HIP_CHECK(hipStreamSynchronize(st));
-    }
+    if ((rc = h->clip_off.ensure(need))) return rc;
+    RADAD_HIP_CHECK(hipMemcpyAsync(h->clip_off.p, h->pin[slot], need, hipMemcpyHostToDevice, st));
+    RADAD_HIP_CHECK(hipEventRecord(h->pin_ev[slot], st));
+    h->pin_next ^= 1;
+    if ((rc = plan_on_device(h, (const int64_t*)h->clip_off.p, n_clips, std::max<int64_t>(n_seg, 1), st))) return rc;
     h->plan_uniform = uniform;
+    h->plan_on_device = false;
     h->plan_key.assign(clip_offsets, clip_offsets + n_clips + 1);
-    h->plan_nseg = (int64_t)seg_start.size();
+    h->plan_nseg = n_seg;
     return RADAD_OK;
 }
 
@@ -617,6 +712,7 @@ static int upload_plan_explicit(radad_embed_t h, const int64_t* seg_start, const
         RADAD_REQUIRE(seg_valid[i] >= 0 && seg_valid[i] <= h->cfg.segment_length && seg_start[i] >= 0,
                       "segment %lld: bad start/valid", (long long)i);
     h->plan_key.clear();
+    h->plan_on_device = false;
     RADAD_HIP_CHECK(hipStreamSynchronize(st));
     int rc;
     if ((rc = upload(h->seg_start, seg_start, n_seg * sizeof(int64_t), st))) return rc;
@@ -629,7 +725,8 @@ static int upload_plan_explicit(radad_embed_t h, const int64_t* seg_start, const
     return RADAD_OK;
 }
 
-static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, float* norm_out, hipStream_t st) {
+static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, float* norm_out, hipStream_t st,
+                         const int* n_seg_dev = nullptr) {
     int rc;
     if ((rc = h->logmel.ensure((size_t)n_seg * h->nf * N_MELS * sizeof(float)))) return rc;
     if ((rc = h->seg_max.ensure((size_t)n_seg * sizeof(float)))) return rc;
@@ -640,9 +737,11 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.wave = wave_dev; p.seg_start = (const int64_t*)h->seg_start.p; p.seg_valid = (const int*)h->seg_valid.p;
     p.seg_len = h->cfg.segment_length; p.normalize = h->cfg.normalize; p.padded = h->padded; p.nf = h->nf;
     p.basis = h->basis; p.basis_h = h->basis_h; p.fbfrag = h->fbfrag; p.fbfrag_h = h->fbfrag_h; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
-    p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out;
-    const char* dbg = getenv("RADAD_DEBUG_LOGMEL");
-    p.debug = dbg ? atoi(dbg) : 0;
+    p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out; p.n_seg_dev = n_seg_dev;
+    p.debug = 0;
+#ifdef RADAD_DEBUG_HOOKS        // timing experiments only (tools/exp_logmel.sh builds with -DRADAD_DEBUG_HOOKS); never in the shipped library
+    { const char* dbg = getenv("RADAD_DEBUG_LOGMEL"); p.debug = dbg ? atoi(dbg) : 0; }
+#endif
     h->prof_logmel.begin(st);
     if (h->logmel_f32) hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
     else hipLaunchKernelGGL(k_logmel_h, dim3((unsigned)n_seg), dim3(LH_THREADS), logmel_h_lds_bytes(), st, p);
@@ -655,7 +754,7 @@ static void fill_projpool(radad_embed_t h, ProjPoolParams& p) {
     p.logmel = (const float*)h->logmel.p; p.seg_max = (const float*)h->seg_max.p; p.clip_seg = (const int64_t*)h->clip_seg.p;
     p.nf = h->nf; p.T = h->T; p.F = h->cfg.feat_dim; p.wfrag_h = h->wfrag_h; p.wscale = h->wscale; p.bias = h->bias; p.n_levels = h->cfg.n_levels;
     for (int i = 0; i < RADAD_MAX_LEVELS; ++i) p.levels[i] = i < h->cfg.n_levels ? h->cfg.levels[i] : 0;
-    p.pool_mode = h->cfg.pool_mode; p.out = nullptr; p.frames_out = nullptr;
+    p.pool_mode = h->cfg.pool_mode; p.out = nullptr; p.out_bf16 = nullptr; p.frames_out = nullptr; p.n_groups_dev = nullptr;
 }
 
 extern "C" {
@@ -846,7 +945,11 @@ int radad_embed_destroy(radad_embed_t h) {
         if (h->bias) (void)hipFree(h->bias);
         if (h->levels_dev) (void)hipFree(h->levels_dev);
         h->seg_start.release(); h->seg_valid.release(); h->clip_seg.release(); h->logmel.release(); h->seg_max.release();
-        h->seg_ident.release(); h->seg_pool.release();
+        h->seg_pool.release(); h->clip_off.release(); h->n_seg_dev.release();
+        for (int i = 0; i < 2; ++i) {
+            if (h->pin[i]) (void)hipHostFree(h->pin[i]);
+            if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
+        }
         h->misc.release();
         h->prof_logmel.destroy();
         h->prof_pool.destroy();
@@ -858,29 +961,25 @@ int radad_embed_destroy(radad_embed_t h) {
 int radad_embed_output_dim(radad_embed_t h, int* dim) { RADAD_REQUIRE(h && dim, "NULL argument"); *dim = h->nbins * h->cfg.feat_dim; return RADAD_OK; }
 int radad_embed_num_frames(radad_embed_t h, int* frames) { RADAD_REQUIRE(h && frames, "NULL argument"); *frames = h->T; return RADAD_OK; }
 
-int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_host, int64_t n_clips,
-                        float* out_dev, void* stream) {
-    RADAD_REQUIRE(h, "NULL handle");
-    RADAD_REQUIRE(n_clips >= 0, "radad_embed_forward: n_clips < 0");
-    if (n_clips == 0) return RADAD_OK;
-    RADAD_REQUIRE(wave_dev && clip_offsets_host && out_dev, "radad_embed_forward: NULL buffer");
-    std::lock_guard<std::mutex> lk(h->mu);
-    DeviceGuard g(h->device);
-    hipStream_t st = (hipStream_t)stream;
-    int rc = build_plan(h, clip_offsets_host, n_clips, st);
-    if (rc) return rc;
-    if ((rc = launch_logmel(h, wave_dev, h->plan_nseg, nullptr, st))) return rc;
+// log-mel + projection/pooling/segment mean over the plan held by the handle.  n_groups_x: clips (uniform batches: one
+// workgroup pools all segments of a clip) or an upper bound on the segments (ragged: pooled per segment, then averaged).
+static int embed_run(radad_embed_t h, const float* wave_dev, int64_t n_clips, int64_t n_seg_grid, bool per_clip, void* out_dev,
+                     int out_dtype, const int* n_seg_dev, hipStream_t st) {
+    int rc;
+    if ((rc = launch_logmel(h, wave_dev, n_seg_grid, nullptr, st, n_seg_dev))) return rc;
     ProjPoolParams p;
     fill_projpool(h, p);
     const int out_dim = h->nbins * h->cfg.feat_dim;
+    const bool bf16 = out_dtype == RADAD_OUT_BF16;
     int64_t n_groups = n_clips;           // workgroups along x: clips, or segments for a ragged batch
-    if (h->plan_uniform) {
-        p.out = out_dev;
+    if (per_clip) {
+        if (bf16) p.out_bf16 = (unsigned short*)out_dev; else p.out = (float*)out_dev;
     } else {
-        if ((rc = h->seg_pool.ensure((size_t)h->plan_nseg * out_dim * sizeof(float)))) return rc;
+        if ((rc = h->seg_pool.ensure((size_t)n_seg_grid * out_dim * sizeof(float)))) return rc;
         p.out = (float*)h->seg_pool.p;
-        p.clip_seg = (const int64_t*)h->seg_ident.p;
-        n_groups = h->plan_nseg;
+        p.clip_seg = nullptr;             // one group per segment
+        p.n_groups_dev = n_seg_dev;
+        n_groups = n_seg_grid;
     }
     h->prof_pool.begin(st);
     if (h->cfg.feat_dim > 256)
@@ -888,12 +987,55 @@ int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* c
                            projpool_lds_bytes(16), st, p);
     else
         hipLaunchKernelGGL((k_proj_pool<false, 8>), dim3((unsigned)n_groups, 1), dim3(512), projpool_lds_bytes(8), st, p);
-    if (!h->plan_uniform)                 // pipeline.py:411: mean over each clip's segment vectors, in segment order
+    if (!per_clip)                        // pipeline.py:411: mean over each clip's segment vectors, in segment order
         hipLaunchKernelGGL(k_group_mean, dim3((unsigned)n_clips, (unsigned)((out_dim + 255) / 256)), dim3(256), 0, st,
-                           (const float*)h->seg_pool.p, (const int64_t*)h->clip_seg.p, out_dim, out_dev);
+                           (const float*)h->seg_pool.p, (const int64_t*)h->clip_seg.p, out_dim, bf16 ? nullptr : (float*)out_dev,
+                           bf16 ? (unsigned short*)out_dev : nullptr);
     h->prof_pool.end(st);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
+}
+
+int radad_embed_forward_ex(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_host, int64_t n_clips,
+                           void* out_dev, int out_dtype, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    RADAD_REQUIRE(n_clips >= 0, "radad_embed_forward: n_clips < 0");
+    RADAD_REQUIRE(out_dtype == RADAD_OUT_F32 || out_dtype == RADAD_OUT_BF16, "radad_embed_forward: unsupported output dtype %d", out_dtype);
+    if (n_clips == 0) return RADAD_OK;
+    RADAD_REQUIRE(wave_dev && clip_offsets_host && out_dev, "radad_embed_forward: NULL buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = build_plan(h, clip_offsets_host, n_clips, st);
+    if (rc) return rc;
+    return embed_run(h, wave_dev, n_clips, h->plan_nseg, h->plan_uniform, out_dev, out_dtype, nullptr, st);
+}
+
+int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_host, int64_t n_clips,
+                        float* out_dev, void* stream) {
+    return radad_embed_forward_ex(h, wave_dev, clip_offsets_host, n_clips, out_dev, RADAD_OUT_F32, stream);
+}
+
+int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_dev, int64_t n_clips,
+                            int64_t n_samples_total, void* out_dev, int out_dtype, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    RADAD_REQUIRE(n_clips >= 0 && n_samples_total >= 0, "radad_embed_forward_dev: negative size");
+    RADAD_REQUIRE(out_dtype == RADAD_OUT_F32 || out_dtype == RADAD_OUT_BF16, "radad_embed_forward_dev: unsupported output dtype %d", out_dtype);
+    if (n_clips == 0) return RADAD_OK;
+    RADAD_REQUIRE(wave_dev && clip_offsets_dev && out_dev, "radad_embed_forward_dev: NULL buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    hipStream_t st = (hipStream_t)stream;
+    // a clip of N samples has max(1, (N - L)//hop + 1) <= N/hop + 1 segments: the grids and buffers are sized for that
+    // bound, the kernels read the true count from the device
+    const int64_t seg_cap = n_samples_total / h->cfg.hop_length + n_clips;
+    RADAD_REQUIRE(seg_cap < (1ll << 31), "radad_embed_forward_dev: too many segments in one batch");
+    int rc = plan_on_device(h, clip_offsets_dev, n_clips, seg_cap, st);
+    if (rc) return rc;
+    h->plan_key.clear();
+    h->plan_on_device = true;
+    h->plan_nseg = seg_cap;
+    return embed_run(h, wave_dev, n_clips, seg_cap, false, out_dev, out_dtype, (const int*)h->n_seg_dev.p, st);
 }
 
 int radad_embed_profile(radad_embed_t h, int enable) {
@@ -1016,7 +1158,7 @@ int radad_group_mean(const float* in_dev, const int64_t* group_offsets_host, int
     int rc = RADAD_OK;
     if (hipMemcpyAsync(tmp, group_offsets_host, off_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { radad_set_error("H2D copy failed"); rc = RADAD_EHIP; }
     if (!rc) {
-        hipLaunchKernelGGL(k_group_mean, dim3((unsigned)n_groups, (unsigned)((dim + 255) / 256)), dim3(256), 0, st, in_dev, tmp, dim, out_dev);
+        hipLaunchKernelGGL(k_group_mean, dim3((unsigned)n_groups, (unsigned)((dim + 255) / 256)), dim3(256), 0, st, in_dev, tmp, dim, out_dev, (unsigned short*)nullptr);
         if (hipGetLastError() != hipSuccess) { radad_set_error("k_group_mean launch failed"); rc = RADAD_EHIP; }
     }
     if (hipStreamSynchronize(st) != hipSuccess && !rc) { radad_set_error("k_group_mean failed"); rc = RADAD_EHIP; }

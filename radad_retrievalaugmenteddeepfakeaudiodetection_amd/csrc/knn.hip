@@ -173,7 +173,7 @@ __device__ __forceinline__ void knn_tile_gemm_pipelined(const TileCtx& c, __amdg
     for (int kc = 0; kc < c.nk; ++kc) {
         const int buf = gbuf & 1;
         const bool more = kc + 1 < c.nk;
-        if (!(c.debug & 2)) {
+        if (!RADAD_DBG(c.debug, 2)) {
             if (more) gload(cur_desc, kc + 1);
             else if (has_next) gload(next_desc, 0);
         }
@@ -193,8 +193,8 @@ __device__ __forceinline__ void knn_tile_gemm_pipelined(const TileCtx& c, __amdg
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
             }
         }
-        if ((more || has_next) && !(c.debug & 4)) swrite(buf ^ 1);
-        if (!(c.debug & 8)) __syncthreads();
+        if ((more || has_next) && !RADAD_DBG(c.debug, 4)) swrite(buf ^ 1);
+        if (!RADAD_DBG(c.debug, 8)) __syncthreads();
         ++gbuf;
     }
 }
@@ -278,7 +278,7 @@ __device__ __forceinline__ void knn_tile_gemm_dma(const DmaCtx& c, __amdgpu_buff
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     for (int kc = 0; kc < c.nk; ++kc) {
         const int buf = gbuf & 1;
-        if (!(c.debug & 2)) {
+        if (!RADAD_DBG(c.debug, 2)) {
             if (kc + 1 < c.nk) dma_issue(c, cur_desc, q_desc, sA, sB, buf ^ 1, kc + 1);
             else if (has_next) dma_issue(c, next_desc, q_desc, sA, sB, buf ^ 1, 0);
         }
@@ -310,7 +310,7 @@ __device__ __forceinline__ void knn_tile_gemm_dma(const DmaCtx& c, __amdgpu_buff
                 }
             }
         }
-        if (!(c.debug & 8)) __syncthreads();      // waits vmcnt(0): the DMA issued above has landed for everyone
+        if (!RADAD_DBG(c.debug, 8)) __syncthreads();      // waits vmcnt(0): the DMA issued above has landed for everyone
         ++gbuf;
         if (kc == 0) after_first_barrier();       // work deferred from the previous tile's epilogue (no barriers inside)
     }
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
         const bool has_next = row0 + KT_M < chunk_end;
         knn_tile_gemm_dma<F16>(dc, tile_desc(row0), tile_desc(row0 + KT_M), has_next, q_desc, sA, sB, gbuf, acc,
                           [&]() { if (pending) { drain(); pending = false; } });
-        if (p.debug & 1) {      // timing experiment: keep the accumulators alive, skip the epilogue
+        if (RADAD_DBG(p.debug, 1)) {      // timing experiment: keep the accumulators alive, skip the epilogue
             if (acc[0][0][0] + acc[0][1][5] + acc[1][0][9] + acc[1][1][15] == 12345.678f) s_thr[tid & 127] = 1.f;
             continue;
         }
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
     }
 }
 
-#include "knn_wide.inc"
+#include "knn_hi.inc"
 
 // ---- small-batch scan (nq <= 16: the online `predict` case, pipeline.py:1038-1054) ------------------------------
 // With a handful of queries the scan is HBM-bound (2 flop per stored byte per query), so the 128-query tile above
@@ -786,27 +786,40 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_f32_smallq(SmallQParams p
 constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float2) * KT_N * CAND_CAP + sizeof(float) * KT_N + sizeof(int) * KT_N + 16; }
 
 // ---- merge of sorted partial lists -----------------------------------------------------------------------
-// element (part, q, j) of a list sits at [part*sp + q*sq + j]; lists are sorted best-first and padded with
-// sentinels.  One wave per query; each lane walks the heads of the lists part = lane, lane+64, ...
+// element j of partial list `part` of query q sits at [(q*n_parts + part)*part_len + j]; lists are sorted best-first by
+// (score, -row) and padded with sentinels.  One wave per query; each lane walks the heads of lists lane, lane+64, ...
 //
-// k_merge_refine (inside radad_knn_search): picks the `ksel` best fp32 candidates of the n_splits partial lists
-//   (ksel = k + KNN_MARGIN), RE-SCORES them in float64 straight from the stored rows (L2 as sum (q-y)^2, no
-//   cancellation) and ranks them by (float64 distance, id).  The fp32 MFMA scan is thus only a filter: the final
-//   order and the reported distances are those of an exact float64 brute force unless two of the k best
-//   differ from more than KNN_MARGIN others by less than fp32 rounding (never observed; a tie in the data is
-//   identical in both precisions and resolves to the lower id either way).
+// k_merge_refine (inside radad_knn_search): the scan is a FILTER, this kernel decides.  With a = the scan's score and
+//   eps(q) a bound on |a - exact score| (k_hi_rows), a_k the k-th best a over all lists:
+//     * every row of the exact top-k has a >= tau = a_k - 2 eps   (the k rows with the best a have exact scores >= a_k - eps,
+//       so the exact k-th score is >= a_k - eps, and a row that reaches it has a >= a_k - 2 eps);
+//     * so all listed rows with a >= tau are RE-SCORED in float64 straight from the stored rows (L2 as sum (q-y)^2, no
+//       cancellation) and ranked by (float64 distance, id);
+//     * the result is CERTIFIED to be the exact float64 brute force when no unlisted row can have a >= tau: no list was
+//       used up by the selection while full (its tail could hide such rows), the scan's admission floor thr_init is
+//       <= tau (rows below the floor were never listed), the scan dropped nothing for this query (qflag), and the
+//       candidate buffer (cap) sufficed.  Uncertified queries are appended to flag_sel for the exact kernel below.
+//   eps == nullptr (IVF list scans, k > 128): legacy behaviour -- the `cap` best candidates are re-scored, no certificate.
 // k_merge_lists<KeyT> (radad_topk_merge / _f64): plain P-way merge of final per-shard lists, no rescoring.
-constexpr int KNN_MARGIN = 6;
+constexpr int KNN_MARGIN = 6;            // spare entries of a (query, chunk) list on the fp32 tile kernels
+constexpr int KNN_CERT_EXTRA = 32;       // candidates beyond k the certified re-rank can take before it gives up, at least ...
+constexpr int KNN_CERT_CAP = 128;        // ... and this many in all: stores of near-duplicates (the benchmark plants 2048 rows
+                                         // within 2e-3 of every query) put ~50 rows within 2 eps of the k-th
+constexpr int KNN_CERT_MAX_K = 128;      // largest k the certificate + exact kernel cover
 constexpr int KW_SAMPLE_BLOCKS = 1024;   // workgroups of the threshold pre-pass, at most (4 waves of one-tile workgroups)
-constexpr int KW_SAMPLE_SPLITS = 64;    // one-tile splits of the threshold pre-pass of the wide kernel (<= 16384 rows)
+constexpr int KW_SAMPLE_SPLITS = 64;     // one-tile splits of the threshold pre-pass (<= 16384 rows)
 
 struct RefineParams {
     const float* score;       // [nq, n_parts, part_len] fp32 scan scores (larger is better), each list sorted
     const int* idx;           // [nq, n_parts, part_len] local row or IDX_SENTINEL
-    int n_parts, ksel, k, dim, l2;
-    int part_len;             // entries per partial list; < ksel when the scan kept truncated lists (see `flags`)
-    int* flags;               // optional [nq]: 1 when a truncated list was used up by the selection (it may hide better rows)
-    int* flag_count;          // optional [1]: number of flagged queries (atomicAdd)
+    int n_parts, k, dim, l2;
+    int part_len;             // entries per partial list
+    int cap;                  // candidates that can be re-scored per query (>= k)
+    const float* eps;         // [nq] error bound of the scan scores, or nullptr = legacy mode (exactly `cap` candidates)
+    const float* thr_init;    // optional [nq]: admission floor of the scan (rows below it were never listed)
+    const int* qflag;         // optional [nq]: the scan dropped a candidate of this query
+    int* flag_count;          // certified mode: [1] number of uncertified queries (atomicAdd) ...
+    int* flag_sel;            // ... and their indices, in arrival order
     int64_t nq;
     const void* db;           // stored rows (normalised for cosine); fp16 when db_f16
     int db_f16;
@@ -825,17 +838,21 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
     const int wave = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * p.waves_per_block + wave;
     if (wave >= p.waves_per_block || q >= p.nq) return;
-    // per-wave LDS: double key[ksel] | int id[ksel] | int pos[n_parts]
-    const size_t per_wave = (size_t)p.ksel * 12 + (size_t)p.n_parts * 4;
+    // per-wave LDS: double key[cap] | int id[cap] | int pos[n_parts]
+    const size_t per_wave = (size_t)p.cap * 12 + (size_t)p.n_parts * 4;
     char* base = smem_m + (((size_t)wave * per_wave + 15) & ~(size_t)15) + (size_t)wave * 16;
     double* c_key = reinterpret_cast<double*>(base);
-    int* c_id = reinterpret_cast<int*>(base + (size_t)p.ksel * 8);
-    int* s_pos = c_id + p.ksel;
+    int* c_id = reinterpret_cast<int*>(base + (size_t)p.cap * 8);
+    int* s_pos = c_id + p.cap;
     for (int i = lane; i < p.n_parts; i += 64) s_pos[i] = 0;
 
-    // 1) the ksel best fp32 candidates (a wave only touches its own LDS slice: program order suffices)
+    // 1) candidates in descending scan order (a wave only touches its own LDS slice: program order suffices)
+    const bool cert = p.eps != nullptr;
+    const float two_eps = cert ? 2.f * p.eps[q] : 0.f;
+    float tau = -INFINITY;                   // defined once k candidates are in
     int nsel = 0;
-    for (int o = 0; o < p.ksel; ++o) {
+    bool more = false;                       // a head >= tau was left behind because the buffer is full
+    for (;;) {
         float bs = -INFINITY;
         int bi = IDX_SENTINEL, bp = -1;
         for (int part = lane; part < p.n_parts; part += 64) {
@@ -854,26 +871,31 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
             const int op = __shfl_xor(bp, ofs, 64);
             if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
         }
-        if (bp < 0) break;                       // every list exhausted (wave-uniform)
+        if (bp < 0) break;                                   // every list exhausted (wave-uniform)
+        if (cert && nsel >= p.k && bs < tau) break;          // everything left is below tau
+        if (nsel >= p.cap) { more = cert; break; }
         if ((bp & 63) == lane) s_pos[bp] += 1;
         if (lane == 0) c_id[nsel] = bi;
         ++nsel;
+        if (cert && nsel == p.k) tau = bs - two_eps;
     }
-    // Truncated lists (part_len < ksel): a list the selection consumed completely -- and that was full -- may hide rows that
-    // beat the last ones selected; everything else it hides is below its own last entry, hence below every selected one.
-    if (p.flags) {
-        int bad = 0;
+    if (cert) {
+        // a list the selection consumed completely -- and that was full -- may hide rows with a >= tau; everything else
+        // a list hides is below its next head, hence below tau
+        int bad = more ? 1 : 0;
         for (int part = lane; part < p.n_parts; part += 64)
             if (s_pos[part] >= p.part_len &&
                 p.idx[((int64_t)q * p.n_parts + part) * p.part_len + p.part_len - 1] != IDX_SENTINEL) bad = 1;
 #pragma unroll
         for (int ofs = 32; ofs > 0; ofs >>= 1) bad |= __shfl_xor(bad, ofs, 64);
-        if (lane == 0) {
-            p.flags[q] = bad;
-            if (bad) atomicAdd(p.flag_count, 1);
+        if (p.thr_init) {
+            const float fl = p.thr_init[q];
+            if (fl > -INFINITY && !(nsel >= p.k && fl <= tau)) bad = 1;      // rows below the floor are unlisted
         }
+        if (p.qflag && p.qflag[q]) bad = 1;
+        if (bad && lane == 0) p.flag_sel[atomicAdd(p.flag_count, 1)] = (int)q;
     }
-    // 2) float64 re-score of the survivors
+    // 2) float64 re-score of the candidates
     const float* qrow = p.q + q * p.dim;
     for (int c = 0; c < nsel; ++c) {
         double acc = 0.0;
@@ -917,6 +939,169 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
         p.out_dist[q * p.k + o] = p.l2 ? INFINITY : -INFINITY;
         p.out_idx[q * p.k + o] = -1;
         if (p.out_key) p.out_key[q * p.k + o] = p.l2 ? (double)INFINITY : -(double)INFINITY;
+    }
+}
+
+// ---- exact float64 search of the queries the certificate rejected --------------------------------------------------
+// Driven entirely from the device: the number of queries (*count) and their indices (sel) were written by
+// k_merge_refine; the launch geometry is fixed, workgroups with nothing to do leave at once.  Slice s of the store
+// (n_slices row ranges) is scanned by workgroups (s, y); workgroup (s, y) takes the query groups y, y + gridDim.y, ...
+// of `group` (<= 8) queries each.  A wave reads one row per step (coalesced), every lane multiplies its elements with
+// the group's queries from LDS in float64, a butterfly sum leaves the (row, query) scores in all lanes; each wave keeps
+// its exact top-k per query as a sorted LDS list (wave-cooperative insertion), the workgroup merges its waves' lists
+// and writes one list per (query slot, slice).  k_exact_merge then merges the slices and overwrites the query's results.
+// Keys are "larger is better" doubles (inner product, or minus the squared distance); order (key desc, id asc).
+constexpr int KX_THREADS = 512;
+constexpr int KX_WAVES = KX_THREADS / 64;
+constexpr int KX_SLICES = 64;
+constexpr int KX_GROUPS_Y = 4;
+
+struct ExactParams {
+    const void* db; int db_f16;
+    const float* q;            // [nq][dim] fp32 queries (normalised for cosine)
+    const int* sel;            // [*count] query indices
+    const int* count;
+    int64_t n; int dim, k, l2, group;
+    int64_t slice_rows;
+    double* pkey;              // [nq][KX_SLICES][k]
+    int* pidx;
+    int64_t id_base;
+    float* out_dist; int64_t* out_idx; double* out_key;
+};
+
+__device__ __forceinline__ bool kx_better(double ka, int ia, double kb, int ib) { return ka > kb || (ka == kb && ia < ib); }
+
+__global__ __launch_bounds__(KX_THREADS) void k_exact_scan(ExactParams p) {
+    const int count = *p.count;
+    if (count <= 0) return;
+    extern __shared__ __attribute__((aligned(16))) char smem_x[];
+    const int G = p.group;
+    float* sQ = reinterpret_cast<float*>(smem_x);                                   // [G][dim]
+    double* sKey = reinterpret_cast<double*>(smem_x + (size_t)G * p.dim * 4);       // [KX_WAVES][G][k]
+    int* sId = reinterpret_cast<int*>(sKey + (size_t)KX_WAVES * G * p.k);           // [KX_WAVES][G][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r_begin = (int64_t)blockIdx.x * p.slice_rows;
+    const int64_t r_end = min(r_begin + p.slice_rows, p.n);
+    const int n_groups = (count + G - 1) / G;
+    const int nv = p.dim >> 2;
+    for (int g = blockIdx.y; g < n_groups; g += gridDim.y) {
+        const int ng = min(G, count - g * G);
+        __syncthreads();
+        for (int i = tid; i < ng * nv; i += KX_THREADS) {
+            const int qq = i / nv, c4 = i % nv;
+            reinterpret_cast<f32x4*>(sQ + (size_t)qq * p.dim)[c4] =
+                reinterpret_cast<const f32x4*>(p.q + (int64_t)p.sel[g * G + qq] * p.dim)[c4];
+        }
+        double* wKey = sKey + (size_t)wave * G * p.k;
+        int* wId = sId + (size_t)wave * G * p.k;
+        for (int i = lane; i < G * p.k; i += 64) { wKey[i] = -INFINITY; wId[i] = IDX_SENTINEL; }
+        __syncthreads();
+        for (int64_t row = r_begin + wave; row < r_end; row += KX_WAVES) {
+            double part[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part[j] = 0.0;
+            for (int i = lane; i < nv; i += 64) {
+                f32x4 y;
+                if (p.db_f16) {
+                    const f16x4 h4 = reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.db) + row * p.dim)[i];
+                    y = f32x4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+                } else {
+                    y = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.db) + row * p.dim)[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < ng) {
+                        const f32x4 x = reinterpret_cast<const f32x4*>(sQ + (size_t)j * p.dim)[i];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (p.l2) { const double d = (double)x[e] - (double)y[e]; part[j] -= d * d; }
+                            else part[j] += (double)x[e] * (double)y[e];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j < ng) {
+                    double v = part[j];
+#pragma unroll
+                    for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_xor(v, ofs, 64);
+                    // wave-uniform from here: insert (v, row) into the sorted list of query j when it beats the k-th entry
+                    double* lk = wKey + (size_t)j * p.k;
+                    int* li = wId + (size_t)j * p.k;
+                    if (kx_better(v, (int)row, lk[p.k - 1], li[p.k - 1])) {
+                        // lane l looks after entries l, l + 64 (k <= 128): read all, count the better ones, shift, write
+                        double e0 = -INFINITY, e1 = -INFINITY;
+                        int i0 = IDX_SENTINEL, i1 = IDX_SENTINEL;
+                        if (lane < p.k) { e0 = lk[lane]; i0 = li[lane]; }
+                        if (lane + 64 < p.k) { e1 = lk[lane + 64]; i1 = li[lane + 64]; }
+                        const bool b0 = lane < p.k && kx_better(e0, i0, v, (int)row);
+                        const bool b1 = lane + 64 < p.k && kx_better(e1, i1, v, (int)row);
+                        const int pos = __popcll(__ballot(b0)) + __popcll(__ballot(b1));
+                        if (lane < p.k && !b0 && lane + 1 < p.k) { lk[lane + 1] = e0; li[lane + 1] = i0; }
+                        if (lane + 64 < p.k && !b1 && lane + 65 < p.k) { lk[lane + 65] = e1; li[lane + 65] = i1; }
+                        if (lane == (pos & 63)) { lk[pos] = v; li[pos] = (int)row; }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // wave j merges the KX_WAVES lists of query j (lane 0, serial: k * 8 comparisons) into the slice's partial list
+        if (wave < ng && lane == 0) {
+            int pos[KX_WAVES];
+#pragma unroll
+            for (int w = 0; w < KX_WAVES; ++w) pos[w] = 0;
+            const int64_t ob = ((int64_t)(g * G + wave) * KX_SLICES + blockIdx.x) * p.k;
+            for (int o = 0; o < p.k; ++o) {
+                double bk = -INFINITY; int bi = IDX_SENTINEL, bw = -1;
+#pragma unroll
+                for (int w = 0; w < KX_WAVES; ++w) {
+                    if (pos[w] < p.k) {
+                        const double kk = sKey[((size_t)w * G + wave) * p.k + pos[w]];
+                        const int ii = sId[((size_t)w * G + wave) * p.k + pos[w]];
+                        if (ii != IDX_SENTINEL && (bw < 0 || kx_better(kk, ii, bk, bi))) { bk = kk; bi = ii; bw = w; }
+                    }
+                }
+                p.pkey[ob + o] = bw < 0 ? -INFINITY : bk;
+                p.pidx[ob + o] = bw < 0 ? IDX_SENTINEL : bi;
+                if (bw >= 0) {
+#pragma unroll
+                    for (int w = 0; w < KX_WAVES; ++w) if (w == bw) ++pos[w];
+                }
+            }
+        }
+    }
+}
+
+// one wave per rejected query: merge its KX_SLICES partial lists, overwrite the query's output rows
+__global__ __launch_bounds__(256) void k_exact_merge(ExactParams p) {
+    const int count = *p.count;
+    const int lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= count) return;
+    static_assert(KX_SLICES == 64, "one list per lane");
+    const int64_t q = p.sel[slot];
+    const double* lk = p.pkey + ((int64_t)slot * KX_SLICES + lane) * p.k;
+    const int* li = p.pidx + ((int64_t)slot * KX_SLICES + lane) * p.k;
+    int pos = 0;
+    for (int o = 0; o < p.k; ++o) {
+        double hk = -INFINITY; int hi = IDX_SENTINEL;
+        if (pos < p.k) { hk = lk[pos]; hi = li[pos]; }
+        double bk = hk; int bi = hi;
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+            const double ok = __shfl_xor(bk, ofs, 64);
+            const int oi = __shfl_xor(bi, ofs, 64);
+            if (oi != IDX_SENTINEL && (bi == IDX_SENTINEL || kx_better(ok, oi, bk, bi))) { bk = ok; bi = oi; }
+        }
+        if (bi != IDX_SENTINEL && hi == bi) ++pos;          // ids are unique: exactly one lane advances
+        if (lane == 0) {
+            const bool none = bi == IDX_SENTINEL;
+            const double d = none ? (p.l2 ? (double)INFINITY : -(double)INFINITY) : (p.l2 ? -bk : bk);
+            p.out_dist[q * p.k + o] = (float)d;
+            p.out_idx[q * p.k + o] = none ? -1 : (int64_t)bi + p.id_base;
+            if (p.out_key) p.out_key[q * p.k + o] = d;
+        }
     }
 }
 
@@ -1114,18 +1299,26 @@ struct radad_knn_s {
     int f16 = 0;              // 1: rows are stored as IEEE fp16 (config.use_float16, vector_database.py:80)
     char* rows = nullptr;     // [capacity, dim] fp32 or fp16
     float* ynorm = nullptr;
-    // split-f16 copy of an fp32 store for the wide scan (knn_wide.inc): built lazily, rows [0, split_rows) are current
-    _Float16* split = nullptr;   // [split_cap][dim/32][hi32|lo32]
-    float* rscale = nullptr;     // [split_cap] 2^-e per row
-    int64_t split_rows = 0, split_cap = 0;
-    int split_off = 0;           // 1: disabled (RADAD_KNN_SPLIT=0, or its allocation failed)
+    // f16 "hi plane" of an fp32 store for the certified scan (knn_hi.inc): built lazily, rows [0, hi_rows) are current
+    _Float16* hi = nullptr;      // [hi_cap][dim]
+    float* rscale = nullptr;     // [hi_cap] 2^-e per row (nullptr for cosine stores: one scale, 2^-14)
+    int64_t hi_rows = 0, hi_cap = 0;
+    int hi_off = 0;              // 1: disabled (RADAD_KNN_HI=0, or its allocation failed)
+    unsigned* stat = nullptr;    // device [2] float bits: max |y|, max |y - yh| over rows [0, stat_rows)
+    int64_t stat_rows = 0;
+    // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
+    // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
+    int* host_count = nullptr;   // pinned [1]
+    hipEvent_t ev_count = nullptr, ev_done = nullptr;
+    bool count_pending = false, done_recorded = false;
+    int64_t count_nq = 0;        // batch size of the search host_count belongs to
+    int hi_skip = 0;             // searches left on the fp32 kernels after the certified scan rejected too many queries
     size_t esize() const { return f16 ? 2 : 4; }
     size_t row_bytes() const { return (size_t)dim * esize(); }
     // search workspace (grown on demand, reused)
     void* ws = nullptr;
     size_t ws_bytes = 0;
     int last_qtiles = 0, last_splits = 0, last_threads = KNN_THREADS;
-    int last_recheck = 0;      // queries of the most recent truncated-list search that were searched again (see knn_search_locked)
     EventRing prof;
     std::mutex mu;
 };
@@ -1142,6 +1335,7 @@ static int knn_realloc(radad_knn_t h, int64_t cap) {
         radad_set_error("hipMalloc of %lld norms failed", (long long)cap);
         return RADAD_ENOMEM;
     }
+    (void)hipDeviceSynchronize();       // searches on other streams may still read the old buffers
     if (h->ntotal > 0) {
         RADAD_HIP_CHECK(hipMemcpy(nrows, h->rows, (size_t)h->ntotal * h->row_bytes(), hipMemcpyDeviceToDevice));
         if (nnorm) RADAD_HIP_CHECK(hipMemcpy(nnorm, h->ynorm, (size_t)h->ntotal * sizeof(float), hipMemcpyDeviceToDevice));
@@ -1151,9 +1345,9 @@ static int knn_realloc(radad_knn_t h, int64_t cap) {
     h->rows = nrows;
     h->ynorm = nnorm;
     h->capacity = cap;
-    if (h->split) (void)hipFree(h->split);       // rebuilt lazily for the new capacity
+    if (h->hi) (void)hipFree(h->hi);             // rebuilt lazily for the new capacity
     if (h->rscale) (void)hipFree(h->rscale);
-    h->split = nullptr; h->rscale = nullptr; h->split_rows = 0; h->split_cap = 0;
+    h->hi = nullptr; h->rscale = nullptr; h->hi_rows = 0; h->hi_cap = 0;
     return RADAD_OK;
 }
 
@@ -1177,33 +1371,50 @@ static int knn_workspace(radad_knn_t h, size_t bytes) {
     return RADAD_OK;
 }
 
-// bring the split-f16 copy up to date with the fp32 rows (appends only touch the new rows); false = not available
-static bool knn_ensure_split(radad_knn_t h, hipStream_t st) {
-    if (h->split_off || h->f16 || h->dim % 32 != 0) return false;
-    if (h->split_cap != h->capacity || !h->split) {
-        (void)hipStreamSynchronize(st);
-        if (h->split) (void)hipFree(h->split);
+// store statistics (max |y|, max |y - yh|) and, when wanted, the f16 hi plane, brought up to date with the rows
+// (appends only touch the new rows).  Returns false when the plane was wanted but is not available.
+static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
+    if (!h->stat) {
+        if (hipMalloc(&h->stat, 2 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        (void)hipMemsetAsync(h->stat, 0, 2 * sizeof(unsigned), st);
+        h->stat_rows = 0;
+    }
+    const bool plane = want_plane && !h->hi_off && !h->f16 && h->dim % 64 == 0;
+    if (plane && (h->hi_cap != h->capacity || !h->hi)) {
+        (void)hipDeviceSynchronize();
+        if (h->hi) (void)hipFree(h->hi);
         if (h->rscale) (void)hipFree(h->rscale);
-        h->split = nullptr; h->rscale = nullptr; h->split_rows = 0; h->split_cap = 0;
-        if (hipMalloc(&h->split, (size_t)h->capacity * h->dim * 4) != hipSuccess ||
-            hipMalloc(&h->rscale, (size_t)h->capacity * sizeof(float)) != hipSuccess) {
+        h->hi = nullptr; h->rscale = nullptr; h->hi_rows = 0; h->hi_cap = 0;
+        const bool per_row = h->metric != RADAD_METRIC_COSINE;
+        if (hipMalloc(&h->hi, (size_t)h->capacity * h->dim * 2) != hipSuccess ||
+            (per_row && hipMalloc(&h->rscale, (size_t)h->capacity * sizeof(float)) != hipSuccess)) {
             (void)hipGetLastError();
-            if (h->split) (void)hipFree(h->split);
-            h->split = nullptr; h->rscale = nullptr;
-            h->split_off = 1;           // no room for the second copy: stay on the fp32 tile kernel
-            return false;
+            if (h->hi) (void)hipFree(h->hi);
+            h->hi = nullptr; h->rscale = nullptr;
+            h->hi_off = 1;              // no room for the plane: stay on the fp32 kernels
+        } else {
+            h->hi_cap = h->capacity;
         }
-        h->split_cap = h->capacity;
     }
-    if (h->split_rows < h->ntotal) {
-        const int64_t m = h->ntotal - h->split_rows;
-        hipLaunchKernelGGL(k_split_rows, dim3((unsigned)ceil_div64(m, 4)), dim3(256), 0, st,
-                           (const float*)h->rows + (size_t)h->split_rows * h->dim, h->split + (size_t)h->split_rows * h->dim * 2,
-                           h->rscale + h->split_rows, m, h->dim);
+    const bool have_plane = plane && h->hi;
+    const int64_t from = have_plane ? std::min(h->hi_rows, h->stat_rows) : h->stat_rows;
+    if (from < h->ntotal) {
+        HiRowsParams hp;
+        hp.in = h->rows + (size_t)from * h->row_bytes(); hp.in_f16 = h->f16;
+        hp.hi = have_plane ? h->hi + (size_t)from * h->dim : nullptr;
+        hp.scale_out = (have_plane && h->rscale) ? h->rscale + from : nullptr;
+        hp.stat_max = h->stat; hp.eps_out = nullptr; hp.ystat = nullptr;
+        hp.n = h->ntotal - from; hp.dim = h->dim;
+        // cosine rows have |x| <= 1: one scale for the whole store (no per-score arithmetic in the scan);
+        // an fp16 store is its own plane: statistics only, un-scaled
+        hp.fixed_e = h->f16 ? 0 : (h->metric == RADAD_METRIC_COSINE ? 14 : HI_E_PER_ROW);
+        hp.l2 = 0; hp.exact_ops = h->f16 ? 1 : 0;
+        hipLaunchKernelGGL(k_hi_rows, dim3((unsigned)ceil_div64(hp.n, 4)), dim3(256), 0, st, hp);
         if (hipGetLastError() != hipSuccess) return false;
-        h->split_rows = h->ntotal;
+        h->stat_rows = h->ntotal;
+        if (have_plane) h->hi_rows = h->ntotal;
     }
-    return true;
+    return !want_plane || have_plane || h->f16;
 }
 
 // wide kernel: 256-query tiles, one workgroup per CU; two rounds of workgroups keep the tail short
@@ -1237,7 +1448,19 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
     radad_knn_s* h = new (std::nothrow) radad_knn_s();
     if (!h) { radad_set_error("out of host memory"); return RADAD_ENOMEM; }
     h->dim = dim; h->metric = metric; h->device = device; h->id_base = id_base; h->f16 = store_dtype == RADAD_STORE_F16;
-    { const char* e = getenv("RADAD_KNN_SPLIT"); h->split_off = (e && atoi(e) == 0) ? 1 : 0; }
+    // RADAD_KNN_HI=0 keeps every search on the fp32 kernels (bench.py --scan f32); read once, at creation
+    { const char* e = getenv("RADAD_KNN_HI"); h->hi_off = (e && atoi(e) == 0) ? 1 : 0; }
+    {
+        DeviceGuard g(device);
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->host_count), sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_count, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess) {
+            radad_set_error("radad_knn_create: pinned counter / events could not be created");
+            radad_knn_destroy(h);
+            return RADAD_EHIP;
+        }
+        *h->host_count = 0;
+    }
     *out = h;
     return RADAD_OK;
 }
@@ -1249,8 +1472,12 @@ int radad_knn_destroy(radad_knn_t h) {
         if (h->rows) (void)hipFree(h->rows);
         if (h->ynorm) (void)hipFree(h->ynorm);
         if (h->ws) (void)hipFree(h->ws);
-        if (h->split) (void)hipFree(h->split);
+        if (h->hi) (void)hipFree(h->hi);
         if (h->rscale) (void)hipFree(h->rscale);
+        if (h->stat) (void)hipFree(h->stat);
+        if (h->host_count) (void)hipHostFree(h->host_count);
+        if (h->ev_count) (void)hipEventDestroy(h->ev_count);
+        if (h->ev_done) (void)hipEventDestroy(h->ev_done);
         h->prof.destroy();
     }
     delete h;
@@ -1336,66 +1563,92 @@ int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float
     return radad_knn_search_f64(h, q_dev, nq, k, out_dist_dev, out_idx_dev, nullptr, stream);
 }
 
-static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k, int margin, float* out_dist_dev,
+static int knn_search_core(radad_knn_t h, const void* q_dev, int q_dtype, int64_t nq, int k, int margin, float* out_dist_dev,
                            int64_t* out_idx_dev, double* out_key_dev, void* stream);
-static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int k, int margin, float* out_dist_dev,
-                             int64_t* out_idx_dev, double* out_key_dev, void* stream, bool allow_trunc);
 
 int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev, int64_t* out_idx_dev,
                          double* out_key_dev, void* stream) {
-    return knn_search_core(h, q_dev, nq, k, KNN_MARGIN, out_dist_dev, out_idx_dev, out_key_dev, stream);
+    return knn_search_core(h, q_dev, RADAD_Q_F32, nq, k, KNN_MARGIN, out_dist_dev, out_idx_dev, out_key_dev, stream);
+}
+
+int radad_knn_search_ex(radad_knn_t h, const void* q_dev, int q_dtype, int64_t nq, int k, float* out_dist_dev,
+                        int64_t* out_idx_dev, double* out_key_dev, void* stream) {
+    RADAD_REQUIRE(q_dtype == RADAD_Q_F32 || q_dtype == RADAD_Q_BF16, "radad_knn_search_ex: unsupported query dtype %d", q_dtype);
+    return knn_search_core(h, q_dev, q_dtype, nq, k, KNN_MARGIN, out_dist_dev, out_idx_dev, out_key_dev, stream);
 }
 
 }  // extern "C"
 
-// `margin` spare candidates per query reach the float64 re-rank (KNN_MARGIN for user searches; the IVF coarse quantiser
-// asks for fewer so that nprobe = 32 still fits the 32-entry register lists)
-static int knn_search_core(radad_knn_t h, const float* q_dev, int64_t nq, int k, int margin, float* out_dist_dev,
+// bf16 -> fp32 (exact): queries handed over as bfloat16 (BASELINE config 5) are decoded once, then take the fp32 path
+__global__ __launch_bounds__(256) void k_bf16_to_f32(const unsigned short* __restrict__ in, float* __restrict__ out, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    const u16x4 b = *reinterpret_cast<const u16x4*>(in + i);
+    *reinterpret_cast<f32x4*>(out + i) = f32x4{__uint_as_float((unsigned)b[0] << 16), __uint_as_float((unsigned)b[1] << 16),
+                                               __uint_as_float((unsigned)b[2] << 16), __uint_as_float((unsigned)b[3] << 16)};
+}
+
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// The search proper.  `margin` spare entries per (query, chunk) list on the fp32 tile kernels (KNN_MARGIN for user
+// searches; the IVF coarse quantiser asks for fewer so that nprobe = 32 still fits the 32-entry register lists).
+//
+// Scan (a filter), one of:
+//   certified f16 scan (knn_hi.inc)   batches > 16 queries on stores with >= 64 tiles: hi plane of an fp32 store or the
+//                                     fp16 store itself, 16-entry lists per chunk whatever k is (k <= 128)
+//   k_knn_f32_smallq                  <= 16 queries, fp32 store: HBM-bound streaming
+//   k_knn_f32_reg / k_knn_f32         the fp32 (or fp16-operand) tile kernels, lists of k + margin
+// then k_merge_refine: float64 re-rank of every candidate within 2 eps of the k-th, per-query certificate; then the
+// exact float64 kernel for the queries the certificate rejected (device-driven, usually zero work).  Nothing in here
+// synchronises with the host unless the workspace has to grow.
+static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t nq, int k, int margin, float* out_dist_dev,
                            int64_t* out_idx_dev, double* out_key_dev, void* stream) {
     RADAD_REQUIRE(h, "NULL handle");
     RADAD_REQUIRE(k >= 1 && k <= RADAD_KNN_MAX_K, "radad_knn_search: k=%d outside [1,%d]", k, RADAD_KNN_MAX_K);
     RADAD_REQUIRE(nq >= 0 && nq < (1ll << 31) - KT_N, "radad_knn_search: bad nq");
     if (nq == 0) return RADAD_OK;
-    RADAD_REQUIRE(q_dev && out_dist_dev && out_idx_dev, "radad_knn_search: NULL buffer");
+    RADAD_REQUIRE(q_in && out_dist_dev && out_idx_dev, "radad_knn_search: NULL buffer");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
-    return knn_search_locked(h, q_dev, nq, k, margin, out_dist_dev, out_idx_dev, out_key_dev, stream, true);
-}
-
-// out[sel[i], :] = src[i, :]   (results of the re-searched queries go back to their rows)
-template <typename T>
-__global__ __launch_bounds__(256) void k_scatter_rows(const T* __restrict__ src, const int64_t* __restrict__ sel, int64_t n, int k,
-                                                      T* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n * k) out[sel[i / k] * k + i % k] = src[i];
-}
-
-// the search proper; the caller holds h->mu and has the device selected.
-// allow_trunc: with more than 16 candidates per query wanted (k > 10) the wide kernel still keeps 16-entry lists per store
-// chunk (its 24/32-entry variants spill) and k_merge_refine certifies per query that no chunk's list was used up by the
-// selection; the few queries that fail (>= 17 of their best k+6 rows in one chunk: clustered duplicates) are searched again
-// with full-length lists.  That needs one host synchronisation per call; k <= 10 never takes it.
-static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int k, int margin, float* out_dist_dev,
-                             int64_t* out_idx_dev, double* out_key_dev, void* stream, bool allow_trunc) {
     hipStream_t st = (hipStream_t)stream;
-    if (allow_trunc) h->last_recheck = 0;
+    // one workspace per handle: a search on another stream waits for the previous one (threads are serialised by h->mu,
+    // the device work by this event)
+    if (h->done_recorded) RADAD_HIP_CHECK(hipStreamWaitEvent(st, h->ev_done, 0));
 
+    // how the previous search's certificate fared (its count has long landed; never wait for it here)
+    if (h->count_pending && hipEventQuery(h->ev_count) == hipSuccess) {
+        h->count_pending = false;
+        if (h->hi_skip == 0 && h->count_nq >= 64 && (int64_t)*h->host_count * 4 > h->count_nq) h->hi_skip = 8;
+    }
+    const bool cert = k <= KNN_CERT_MAX_K;      // beyond: legacy k + margin candidates, no certificate
+    const int l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0;
+
+    // ---- choice of the scan -------------------------------------------------------------------------------------
     int n_qtiles, n_splits;
     int64_t chunk_rows;
     knn_geometry(std::max<int64_t>(h->ntotal, 1), nq, &n_qtiles, &n_splits, &chunk_rows);
-    // batches of more than 16 queries take the wide kernel on the f16 matrix pipe: split-f16 copy of an fp32 store (mode 0) or the fp16
-    // store as it is (mode 1); see knn_wide.inc.  RADAD_KNN_SPLIT=0 keeps an fp32 store on the fp32 tile kernel.
-    int wide_mode = -1;
-    // every batch above the small-batch streaming kernel's 16 queries: measured at 1 M x 512, 32 / 64 / 128 queries take
-    // 0.82 / 0.86 / 0.92 ms per search here against 1.30 / 1.35 / 1.54 ms on the fp32 tile kernel (RADAD_WIDE_MIN_Q moves it)
     static const int wide_min_q = [] { const char* e = getenv("RADAD_WIDE_MIN_Q"); return e ? atoi(e) : SQ_NQ + 1; }();
-    if (nq >= wide_min_q && k + margin <= 32 && h->ntotal > 0) {
-        if (h->f16) { if (h->dim % 64 == 0) wide_mode = 1; }
-        else if (knn_ensure_split(h, st)) wide_mode = 0;
+    bool use_hi = false;
+    int s_splits = 0;
+    // (k + margin <= 32: the admission floor is the (k + margin)-th best score of the sample; a lower floor would admit
+    // more than the 8 slots per query and tile can take)
+    if (cert && nq >= wide_min_q && k + margin <= 32 && h->ntotal > 0 && h->dim % 64 == 0 && !h->hi_off) {
+        int wq, ws; int64_t wc;
+        knn_geometry_wide(h->ntotal, nq, &wq, &ws, &wc);
+        // the threshold pre-pass: one tile per workgroup, at most KW_SAMPLE_SPLITS tiles, 1/8 of the store and
+        // KW_SAMPLE_BLOCKS workgroups; the certified scan needs it (its first tile would overflow the slots otherwise)
+        s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
+        s_splits = std::min(s_splits, std::max(8, (KW_SAMPLE_BLOCKS / wq) / 8 * 8));
+        static_assert(KW_SAMPLE_SPLITS * 8 <= 64 * THR_LISTS_PER_LANE, "k_thr_from_parts: lists per lane");
+        if (s_splits >= 8) {
+            if (h->hi_skip > 0) --h->hi_skip;
+            else if (knn_ensure_hi(h, st, true)) { use_hi = true; n_qtiles = wq; n_splits = ws; chunk_rows = wc; }
+        }
     }
-    if (wide_mode >= 0) knn_geometry_wide(h->ntotal, nq, &n_qtiles, &n_splits, &chunk_rows);
-    // small batches (the online predict case) take the HBM-bound streaming kernel: one list per WAVE
-    const bool smallq = !h->f16 && nq <= SQ_NQ && h->dim % 32 == 0 && h->dim <= SQ_MAX_DIM && k + margin <= 32 && h->ntotal > 0;
+    if (!use_hi && cert && !knn_ensure_hi(h, st, false)) { radad_set_error("store statistics could not be computed"); return RADAD_EHIP; }
+    const int ksel = k + margin;                 // list length of the fp32 tile kernels
+    const bool smallq = !use_hi && !h->f16 && nq <= SQ_NQ && h->dim % 32 == 0 && h->dim <= SQ_MAX_DIM && ksel <= 32 && h->ntotal > 0;
     int sq_rows_per_wave = 0;
     if (smallq) {
         const int64_t waves_wanted = 256 * 8;                                     // 8 waves (2 workgroups) per CU
@@ -1405,120 +1658,127 @@ static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int 
         n_splits = (int)ceil_div64(ceil_div64(h->ntotal, rpw), 4);                // workgroups of 4 waves = lists per query
         n_qtiles = 1;
     }
+    const bool f16_tile = !use_hi && h->f16 && ksel <= 32 && h->dim % 64 == 0;
     h->last_qtiles = n_qtiles;
-    h->last_threads = wide_mode >= 0 ? KW_THREADS : (smallq ? SQ_THREADS : KNN_THREADS);
+    h->last_threads = use_hi ? KW_THREADS : (smallq ? SQ_THREADS : KNN_THREADS);
     h->last_splits = n_splits;
+    const int plen = use_hi ? KW_LIST : ksel;    // entries of a partial list
+    const int cap = cert ? std::max(k + KNN_CERT_EXTRA, KNN_CERT_CAP) : ksel;
+    const int xgroup = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(64 * 1024) / ((size_t)h->dim * 4)));
 
-    // workspace: [qn: nq*dim fp32] (cosine) | [qh: nq*dim fp16] (fp16 store) | part_score | part_idx
-    const size_t qn_bytes = h->metric == RADAD_METRIC_COSINE ? (size_t)nq * h->dim * sizeof(float) : 0;
-    // [qh]: fp16 queries (fp16 store) or split-f16 queries + their scales (wide kernel on an fp32 store)
-    const size_t qsplit_bytes = (((size_t)nq * h->dim * 4) + 255) & ~(size_t)255;
-    const size_t qvec_bytes = (((size_t)nq * sizeof(float)) + 255) & ~(size_t)255;
-    // ... | thr_init [nq] | flags [nq] | flag count
-    const size_t qnorm_bytes = (wide_mode == 0 ? qsplit_bytes + qvec_bytes
-                                               : (h->f16 ? ((((size_t)nq * h->dim * 2) + 255) & ~(size_t)255) : 256)) + 2 * qvec_bytes + 256;
-    // (the sample pre-pass writes 16 entries per query for each of its up to 64 tiles into the head of the same arrays)
-    const size_t part_elems = (size_t)nq * std::max<size_t>((size_t)n_splits * (k + margin), wide_mode >= 0 ? (size_t)KW_SAMPLE_SPLITS * 16 : 0);
-    const size_t off_qnorm = (qn_bytes + 255) & ~(size_t)255;
-    const size_t off_ps = off_qnorm + qnorm_bytes;
-    const size_t off_pi = off_ps + ((part_elems * sizeof(float) + 255) & ~(size_t)255);
-    const size_t total = off_pi + part_elems * sizeof(int);
-    if (total > h->ws_bytes) {
-        RADAD_HIP_CHECK(hipStreamSynchronize(st));
-        int rc = knn_workspace(h, total);
+    // ---- workspace: qf (decoded bf16) | qn (normalised) | qh (f16 queries) | qscale | eps | thr_init | qflag |
+    //                 flag_count, flag_sel | part_score | part_idx | exact partial keys | ids
+    const size_t qrow_f32 = al256((size_t)nq * h->dim * sizeof(float));
+    const size_t b_qf = q_dtype == RADAD_Q_BF16 ? qrow_f32 : 0;
+    const size_t b_qn = h->metric == RADAD_METRIC_COSINE ? qrow_f32 : 0;
+    const size_t b_qh = (use_hi || f16_tile) ? al256((size_t)nq * h->dim * 2) : 0;
+    const size_t b_vec = al256((size_t)nq * sizeof(float));
+    const size_t part_elems = (size_t)nq * std::max<size_t>((size_t)n_splits * plen, use_hi ? (size_t)KW_SAMPLE_SPLITS * 16 : 0);
+    const size_t b_part = al256(part_elems * sizeof(float));
+    const size_t b_xk = cert ? al256((size_t)nq * KX_SLICES * k * sizeof(double)) : 0;
+    const size_t b_xi = cert ? al256((size_t)nq * KX_SLICES * k * sizeof(int)) : 0;
+    size_t off = 0;
+    const size_t o_qf = off; off += b_qf;
+    const size_t o_qn = off; off += b_qn;
+    const size_t o_qh = off; off += b_qh;
+    const size_t o_qscale = off; off += b_vec;
+    const size_t o_eps = off; off += b_vec;
+    const size_t o_thr = off; off += b_vec;
+    const size_t o_qflag = off; off += b_vec;          // qflag [nq] int
+    const size_t o_fcount = off; off += 256;           // flag_count (same memset as qflag: contiguous)
+    const size_t o_fsel = off; off += b_vec;
+    const size_t o_ps = off; off += b_part;
+    const size_t o_pi = off; off += b_part;
+    const size_t o_xk = off; off += b_xk;
+    const size_t o_xi = off; off += b_xi;
+    if (off > h->ws_bytes) {
+        RADAD_HIP_CHECK(hipDeviceSynchronize());
+        int rc = knn_workspace(h, off);
         if (rc) return rc;
     }
     char* ws = (char*)h->ws;
-    float* qn = (float*)ws;
-    _Float16* qh = (_Float16*)(ws + off_qnorm);
-    float* ps = (float*)(ws + off_ps);
-    int* pi = (int*)(ws + off_pi);
+    _Float16* qh = (_Float16*)(ws + o_qh);
+    float* qscale = (float*)(ws + o_qscale);
+    float* eps = (float*)(ws + o_eps);
+    float* thr_init = (float*)(ws + o_thr);
+    int* qflag = (int*)(ws + o_qflag);
+    int* flag_count = (int*)(ws + o_fcount);
+    int* flag_sel = (int*)(ws + o_fsel);
+    float* ps = (float*)(ws + o_ps);
+    int* pi = (int*)(ws + o_pi);
 
-    const float* q_use = q_dev;
+    // ---- queries: decode, normalise, round (+ scale) to f16, error bound ------------------------------------------
+    const float* q_use = (const float*)q_in;
     const unsigned rgrid = (unsigned)ceil_div64(nq, 4);
+    if (q_dtype == RADAD_Q_BF16) {
+        float* qf = (float*)(ws + o_qf);
+        const int64_t ne = nq * h->dim;
+        hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)ceil_div64(ne, 1024)), dim3(256), 0, st, (const unsigned short*)q_in, qf, ne);
+        q_use = qf;
+    }
     if (h->metric == RADAD_METRIC_COSINE) {
-        hipLaunchKernelGGL(k_rows_prepare<float>, dim3(rgrid), dim3(256), 0, st, q_dev, qn, (float*)nullptr, nq, h->dim, 2);
+        float* qn = (float*)(ws + o_qn);
+        hipLaunchKernelGGL(k_rows_prepare<float>, dim3(rgrid), dim3(256), 0, st, q_use, qn, (float*)nullptr, nq, h->dim, 2);
         q_use = qn;
     }
     // (|q|^2 is not needed: ranking uses 2 q.y - |y|^2 and the reported distance is re-scored exactly)
-    // fp16 store + DMA tile kernel: the scan multiplies fp16 x fp16 (fp32 accumulate), so it gets an fp16 copy of the
-    // (normalised) queries; the float64 re-rank below still uses the fp32 queries against the decoded rows.
-    const int ksel = k + margin;                 // the scan keeps a few spare candidates for the float64 re-rank
-    // (with fewer than 8 non-empty chunks most queries would exhaust a chunk's list: keep full-length lists there)
-    const bool trunc = allow_trunc && wide_mode >= 0 && ksel > 16 && ceil_div64(h->ntotal, chunk_rows) >= 8;
-    const int plen = trunc ? 16 : ksel;          // entries of a partial list
-    const bool f16_tile = h->f16 && ksel <= 32 && h->dim % 64 == 0;
-    float* qscale = (float*)(ws + off_qnorm + qsplit_bytes);
-    float* thr_init = (float*)(ws + off_ps - 256 - 2 * qvec_bytes);
-    int* flags = (int*)(ws + off_ps - 256 - qvec_bytes);
-    int* flag_count = (int*)(ws + off_ps - 256);
-    if (wide_mode == 0)
-        hipLaunchKernelGGL(k_split_rows, dim3(rgrid), dim3(256), 0, st, q_use, qh, qscale, nq, h->dim);
-    else if (f16_tile)
-        hipLaunchKernelGGL(k_rows_prepare<_Float16>, dim3(rgrid), dim3(256), 0, st, q_use, qh, (float*)nullptr, nq, h->dim, 0);
+    if (cert || use_hi || f16_tile) {
+        HiRowsParams hp;
+        hp.in = q_use; hp.in_f16 = 0;
+        hp.hi = (use_hi || f16_tile) ? qh : nullptr;
+        hp.scale_out = use_hi ? qscale : nullptr;
+        hp.stat_max = nullptr; hp.eps_out = cert ? eps : nullptr; hp.ystat = h->stat;
+        hp.n = nq; hp.dim = h->dim;
+        hp.fixed_e = use_hi ? HI_E_PER_ROW : 0;          // the fp16 tile kernel multiplies un-scaled fp16 queries
+        hp.l2 = l2; hp.exact_ops = (use_hi || f16_tile) ? 0 : 1;
+        hipLaunchKernelGGL(k_hi_rows, dim3(rgrid), dim3(256), 0, st, hp);
+    }
+    if (cert) RADAD_HIP_CHECK(hipMemsetAsync(qflag, 0, b_vec + 256, st));      // qflag and flag_count
     RADAD_HIP_CHECK(hipGetLastError());
 
+    // ---- scan ----------------------------------------------------------------------------------------------------
     KnnParams p;
     p.db = h->rows; p.db_f16 = h->f16; p.ynorm = h->ynorm; p.q = f16_tile ? (const void*)qh : (const void*)q_use; p.n = h->ntotal; p.nq = (int)nq; p.dim = h->dim; p.k = ksel;
-    p.l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0;
+    p.l2 = l2;
     p.n_qtiles = n_qtiles; p.n_splits = n_splits; p.chunk_rows = chunk_rows; p.part_score = ps; p.part_idx = pi;
-    { const char* dbg = getenv("RADAD_DEBUG_KNN"); p.debug = dbg ? atoi(dbg) : 0; }
-    // > 64 KB of dynamic LDS: raise the limit (per device, so on every call).  Lists live in registers when
-    // k + margin fits 16 or 32 entries (k <= 26), otherwise in the partial-result arrays (generic kernel).
+    p.debug = 0;
     const dim3 grid((unsigned)(n_qtiles * n_splits));
-    if (wide_mode >= 0) {
-        KnnWideParams wp;
-        wp.db = wide_mode == 0 ? (const void*)h->split : (const void*)h->rows;
-        wp.rscale = wide_mode == 0 ? h->rscale : nullptr;
-        wp.ynorm = h->ynorm; wp.q = qh; wp.qscale = wide_mode == 0 ? qscale : nullptr;
-        wp.n = h->ntotal; wp.nq = (int)nq; wp.row_bytes = h->dim * (wide_mode == 0 ? 4 : 2); wp.k = plen; wp.l2 = p.l2;
+    if (use_hi) {
+        KnnHiParams wp;
+        wp.db = h->f16 ? (const void*)h->rows : (const void*)h->hi;
+        wp.rscale = h->f16 ? nullptr : h->rscale;
+        wp.uscale = (!h->f16 && h->metric == RADAD_METRIC_COSINE) ? 0x1p-14f : 1.0f;
+        wp.ynorm = h->ynorm; wp.q = qh; wp.qscale = qscale;
+        wp.n = h->ntotal; wp.nq = (int)nq; wp.row_bytes = h->dim * 2; wp.l2 = l2;
         wp.n_qtiles = n_qtiles; wp.n_splits = n_splits; wp.chunk_rows = chunk_rows; wp.part_score = ps; wp.part_idx = pi;
-        wp.thr_init = nullptr;
-        wp.debug = p.debug;
-        // <list entries, mode>: k + margin <= 16 / 24 / 32
-        const int kvar = plen <= 16 ? 0 : (plen <= 24 ? 1 : 2);
-        const void* fns[3][2] = {{reinterpret_cast<const void*>(k_knn_wide<16, 0>), reinterpret_cast<const void*>(k_knn_wide<16, 1>)},
-                                 {reinterpret_cast<const void*>(k_knn_wide<24, 0>), reinterpret_cast<const void*>(k_knn_wide<24, 1>)},
-                                 {reinterpret_cast<const void*>(k_knn_wide<32, 0>), reinterpret_cast<const void*>(k_knn_wide<32, 1>)}};
-        RADAD_HIP_CHECK(hipFuncSetAttribute(fns[kvar][wide_mode], hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
-        auto launch = [&](const KnnWideParams& kp) {
-            const dim3 g((unsigned)(kp.n_qtiles * kp.n_splits));
-            const dim3 b(KW_THREADS);
-            const size_t lds = knn_wide_lds_bytes();
-            if (kvar == 0 && wide_mode == 0) hipLaunchKernelGGL((k_knn_wide<16, 0>), g, b, lds, st, kp);
-            else if (kvar == 0) hipLaunchKernelGGL((k_knn_wide<16, 1>), g, b, lds, st, kp);
-            else if (kvar == 1 && wide_mode == 0) hipLaunchKernelGGL((k_knn_wide<24, 0>), g, b, lds, st, kp);
-            else if (kvar == 1) hipLaunchKernelGGL((k_knn_wide<24, 1>), g, b, lds, st, kp);
-            else if (wide_mode == 0) hipLaunchKernelGGL((k_knn_wide<32, 0>), g, b, lds, st, kp);
-            else hipLaunchKernelGGL((k_knn_wide<32, 1>), g, b, lds, st, kp);
-        };
-        // sample pre-pass: the ksel-th best score over the first rows of the store is a score at least ksel rows reach,
-        // so the full scan may start from it instead of -inf (scores of a (row, query) pair do not depend on the tiling).
+        wp.thr_init = nullptr; wp.qflag = qflag;
+        const int rsc = l2 ? 2 : (wp.rscale ? 1 : 0);
+        const size_t lds = knn_hi_lds_bytes();
+        const void* fns[3] = {reinterpret_cast<const void*>(k_knn_hi<0>), reinterpret_cast<const void*>(k_knn_hi<1>),
+                              reinterpret_cast<const void*>(k_knn_hi<2>)};
+        const void* sfns[3] = {reinterpret_cast<const void*>(k_knn_hi_sample<0>), reinterpret_cast<const void*>(k_knn_hi_sample<1>),
+                               reinterpret_cast<const void*>(k_knn_hi_sample<2>)};
+        RADAD_HIP_CHECK(hipFuncSetAttribute(fns[rsc], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        RADAD_HIP_CHECK(hipFuncSetAttribute(sfns[rsc], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // sample pre-pass: the 16th best score over the first rows of the store is a score at least 16 rows reach, so the
+        // full scan may admit from it instead of -inf (the score of a (row, query) pair does not depend on the tiling).
         // It reuses the head of the partial arrays; the full scan overwrites them afterwards.
-        // One tile per workgroup, so up to 64 splits (256 workgroups at 4 query tiles) cost the same as 16: the sample is as
-        // large as one wave of workgroups allows, at most 1/8 of the store.
-        // ... and no more than KW_SAMPLE_BLOCKS workgroups in all: with many query tiles the sample shrinks (8192 queries x
-        // 125 k rows, the per-rank shape of an 8-GPU run: 256 / 512 / 1024 workgroups -> 3.47 / 3.26 / 3.23 ms per search)
-        int s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
-        s_splits = std::min(s_splits, std::max(8, (KW_SAMPLE_BLOCKS / n_qtiles) / 8 * 8));
-        static_assert(KW_SAMPLE_SPLITS * 8 <= 64 * THR_LISTS_PER_LANE, "k_thr_from_parts: lists per lane");
-        // ... and it only pays when a workgroup of the full scan has several tiles to filter (it costs one tile's latency)
-        if (s_splits >= 8 && chunk_rows >= 8 * KW_M && !(p.debug & 16)) {
-            KnnWideParams sp = wp;
+        {
+            KnnHiParams sp = wp;
             sp.n = (int64_t)s_splits * KW_M; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
-            const dim3 sg((unsigned)(sp.n_qtiles * sp.n_splits));
-            sp.k = 16;                                           // 8 holders x 2 entries per query and tile
-            const void* sfn = wide_mode == 0 ? reinterpret_cast<const void*>(k_knn_wide_sample<0>) : reinterpret_cast<const void*>(k_knn_wide_sample<1>);
-            RADAD_HIP_CHECK(hipFuncSetAttribute(sfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)knn_wide_lds_bytes()));
-            const dim3 sb(KW_THREADS);
-            if (wide_mode == 0) hipLaunchKernelGGL(k_knn_wide_sample<0>, sg, sb, knn_wide_lds_bytes(), st, sp);
-            else hipLaunchKernelGGL(k_knn_wide_sample<1>, sg, sb, knn_wide_lds_bytes(), st, sp);
-            hipLaunchKernelGGL(k_thr_from_parts, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, ps, pi, sp.n_splits * 8, 2, ksel, nq,
-                               thr_init);
+            const dim3 sg((unsigned)(sp.n_qtiles * sp.n_splits)), sb(KW_THREADS);
+            if (rsc == 0) hipLaunchKernelGGL(k_knn_hi_sample<0>, sg, sb, lds, st, sp);
+            else if (rsc == 1) hipLaunchKernelGGL(k_knn_hi_sample<1>, sg, sb, lds, st, sp);
+            else hipLaunchKernelGGL(k_knn_hi_sample<2>, sg, sb, lds, st, sp);
+            hipLaunchKernelGGL(k_thr_from_parts, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, ps, pi, sp.n_splits * 8, 2,
+                               k + margin, nq, thr_init);
             wp.thr_init = thr_init;
         }
+        const dim3 b(KW_THREADS);
         h->prof.begin(st);          // the event pair brackets the full-scan launch only (the kernel the roofline is quoted on)
-        launch(wp);
+        if (rsc == 0) hipLaunchKernelGGL(k_knn_hi<0>, grid, b, lds, st, wp);
+        else if (rsc == 1) hipLaunchKernelGGL(k_knn_hi<1>, grid, b, lds, st, wp);
+        else hipLaunchKernelGGL(k_knn_hi<2>, grid, b, lds, st, wp);
         h->prof.end(st);
     } else if (smallq) {
         SmallQParams sp;
@@ -1565,57 +1825,42 @@ static int knn_search_locked(radad_knn_t h, const float* q_dev, int64_t nq, int 
     }
     RADAD_HIP_CHECK(hipGetLastError());
 
+    // ---- float64 re-rank + certificate ----------------------------------------------------------------------------
     RefineParams m;
-    m.score = ps; m.idx = pi; m.n_parts = n_splits; m.ksel = ksel; m.k = k; m.dim = h->dim; m.l2 = p.l2; m.nq = nq;
-    m.part_len = plen; m.flags = trunc ? flags : nullptr; m.flag_count = trunc ? flag_count : nullptr;
+    m.score = ps; m.idx = pi; m.n_parts = n_splits; m.k = k; m.dim = h->dim; m.l2 = l2; m.nq = nq;
+    m.part_len = plen; m.cap = cap;
+    m.eps = cert ? eps : nullptr; m.thr_init = use_hi ? thr_init : nullptr; m.qflag = (cert && use_hi) ? qflag : nullptr;
+    m.flag_count = flag_count; m.flag_sel = flag_sel;
     m.db = h->rows; m.db_f16 = h->f16; m.q = q_use; m.id_map = nullptr; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
     m.out_key = out_key_dev;
-    if (trunc) RADAD_HIP_CHECK(hipMemsetAsync(flag_count, 0, sizeof(int), st));
-    const size_t per_wave = (((size_t)ksel * 12 + (size_t)n_splits * 4 + 15) & ~(size_t)15) + 16;
+    const size_t per_wave = (((size_t)cap * 12 + (size_t)n_splits * 4 + 15) & ~(size_t)15) + 16;
     m.waves_per_block = (int)std::max<size_t>(1, std::min<size_t>(4, (60 * 1024) / per_wave));
     hipLaunchKernelGGL(k_merge_refine, dim3((unsigned)ceil_div64(nq, m.waves_per_block)), dim3(256),
                        per_wave * m.waves_per_block + 64, st, m);
     RADAD_HIP_CHECK(hipGetLastError());
-    if (!trunc) return RADAD_OK;
 
-    // ---- queries whose truncated lists could not be certified: search them again with full-length lists ----------------
-    int n_flag = 0;
-    RADAD_HIP_CHECK(hipMemcpyAsync(&n_flag, flag_count, sizeof(int), hipMemcpyDeviceToHost, st));
-    RADAD_HIP_CHECK(hipStreamSynchronize(st));
-    h->last_recheck = n_flag;
-    if (n_flag == 0) return RADAD_OK;
-    std::vector<int> fl((size_t)nq);
-    RADAD_HIP_CHECK(hipMemcpy(fl.data(), flags, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost));
-    std::vector<int64_t> sel;
-    for (int64_t i = 0; i < nq; ++i)
-        if (fl[(size_t)i]) sel.push_back(i);
-    const int64_t nf = (int64_t)sel.size();
-    const size_t b_sel = (((size_t)nf * 8) + 255) & ~(size_t)255, b_q = (((size_t)nf * h->dim * 4) + 255) & ~(size_t)255;
-    const size_t b_d = (((size_t)nf * k * 4) + 255) & ~(size_t)255, b_i = (((size_t)nf * k * 8) + 255) & ~(size_t)255;
-    char* tmp = nullptr;
-    if (hipMalloc(&tmp, b_sel + b_q + b_d + 2 * b_i) != hipSuccess) { radad_set_error("hipMalloc of the re-search buffers failed"); return RADAD_ENOMEM; }
-    int64_t* sel_d = (int64_t*)tmp;
-    float* q_t = (float*)(tmp + b_sel);
-    float* d_t = (float*)(tmp + b_sel + b_q);
-    int64_t* i_t = (int64_t*)(tmp + b_sel + b_q + b_d);
-    double* k_t = (double*)(tmp + b_sel + b_q + b_d + b_i);
-    const int keep_qt = h->last_qtiles, keep_sp = h->last_splits, keep_th = h->last_threads;
-    int rc = RADAD_OK;
-    if (hipMemcpy(sel_d, sel.data(), (size_t)nf * 8, hipMemcpyHostToDevice) != hipSuccess) { radad_set_error("H2D copy failed"); rc = RADAD_EHIP; }
-    if (rc == RADAD_OK) {
-        hipLaunchKernelGGL(k_gather_rows<float>, dim3((unsigned)ceil_div64(nf, 4)), dim3(256), 0, st, q_dev, sel_d, nf, nq, (int64_t)0, h->dim, q_t);
-        rc = knn_search_locked(h, q_t, nf, k, margin, d_t, i_t, out_key_dev ? k_t : nullptr, stream, false);
+    // ---- the queries the certificate rejected: exact float64 search, sized and driven by the device-side count ------
+    if (cert) {
+        ExactParams x;
+        x.db = h->rows; x.db_f16 = h->f16; x.q = q_use; x.sel = flag_sel; x.count = flag_count;
+        x.n = h->ntotal; x.dim = h->dim; x.k = k; x.l2 = l2; x.group = xgroup;
+        x.slice_rows = ceil_div64(std::max<int64_t>(h->ntotal, 1), KX_SLICES);
+        x.pkey = (double*)(ws + o_xk); x.pidx = (int*)(ws + o_xi); x.id_base = h->id_base;
+        x.out_dist = out_dist_dev; x.out_idx = out_idx_dev; x.out_key = out_key_dev;
+        const size_t xlds = (size_t)xgroup * h->dim * 4 + (size_t)KX_WAVES * xgroup * k * 12 + 16;
+        RADAD_REQUIRE(xlds <= 160 * 1024, "radad_knn_search: dim %d x k %d too large for the exact kernel", h->dim, k);
+        RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_exact_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
+        hipLaunchKernelGGL(k_exact_scan, dim3(KX_SLICES, KX_GROUPS_Y), dim3(KX_THREADS), xlds, st, x);
+        hipLaunchKernelGGL(k_exact_merge, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, x);
+        RADAD_HIP_CHECK(hipGetLastError());
+        RADAD_HIP_CHECK(hipMemcpyAsync(h->host_count, flag_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        RADAD_HIP_CHECK(hipEventRecord(h->ev_count, st));
+        h->count_pending = true;
+        h->count_nq = nq;
     }
-    if (rc == RADAD_OK) {
-        const unsigned sg = (unsigned)ceil_div64(nf * k, 256);
-        hipLaunchKernelGGL(k_scatter_rows<float>, dim3(sg), dim3(256), 0, st, d_t, sel_d, nf, k, out_dist_dev);
-        hipLaunchKernelGGL(k_scatter_rows<int64_t>, dim3(sg), dim3(256), 0, st, i_t, sel_d, nf, k, out_idx_dev);
-        if (out_key_dev) hipLaunchKernelGGL(k_scatter_rows<double>, dim3(sg), dim3(256), 0, st, k_t, sel_d, nf, k, out_key_dev);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { radad_set_error("re-search scatter failed"); rc = RADAD_EHIP; }
-    }
-    (void)hipFree(tmp);
-    h->last_qtiles = keep_qt; h->last_splits = keep_sp; h->last_threads = keep_th;
-    return rc;
+    RADAD_HIP_CHECK(hipEventRecord(h->ev_done, st));
+    h->done_recorded = true;
+    return RADAD_OK;
 }
 
 extern "C" {
@@ -1706,7 +1951,10 @@ int radad_knn_profile_read(radad_knn_t h, float* ms_out, int cap, int* n_out) {
 
 int radad_knn_last_recheck(radad_knn_t h, int* n_queries) {
     RADAD_REQUIRE(h && n_queries, "NULL argument");
-    *n_queries = h->last_recheck;
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    if (h->count_pending) RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count));
+    *n_queries = h->host_count ? *h->host_count : 0;
     return RADAD_OK;
 }
 
@@ -1813,7 +2061,8 @@ int snap_load_range(radad_knn_t h, const char* path, int64_t row0, int64_t n_row
     DeviceGuard g(h->device);
     RADAD_HIP_CHECK(hipDeviceSynchronize());
     h->ntotal = 0;
-    h->split_rows = 0;                     // the split-f16 copy describes the old contents
+    h->hi_rows = 0; h->stat_rows = 0;      // the hi plane and the statistics describe the old contents
+    if (h->stat) RADAD_HIP_CHECK(hipMemset(h->stat, 0, 2 * sizeof(unsigned)));
     if ((rc = knn_grow(h, n_rows))) return rc;
     const unsigned char* src = map.base + hd.payload_off + (size_t)row0 * rb;
     const size_t total = (size_t)n_rows * rb;

@@ -114,21 +114,38 @@ class MelProjectionFeatureExtractor:
                 pass
 
     # ---- batched device path --------------------------------------------------------------------------
-    def embed_clips(self, wave, clip_offsets: Sequence[int]):
-        """wave: 1-D float32 CUDA tensor holding the clips back to back; clip_offsets: B+1 host ints.
+    def embed_clips(self, wave, clip_offsets, out_dtype=None):
+        """wave: 1-D float32 CUDA tensor holding the clips back to back; clip_offsets: B+1 ints, either on the host
+        (sequence / numpy) or an int64 CUDA tensor -- then the segment plan (segmenter.py:25-39) is built on the device and
+        nothing synchronises with the host.  out_dtype: torch.float32 (default) or torch.bfloat16 (BASELINE config 5).
         Returns the clip embeddings [B, sum(levels)*F] (segment -> embed of pipeline.py:392-414)."""
         import torch
         _lib.require_cuda(wave, "wave")
         if wave.dtype != torch.float32 or not wave.is_contiguous():
             wave = wave.contiguous().float()
+        out_dtype = out_dtype or torch.float32
+        if out_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("out_dtype must be torch.float32 or torch.bfloat16")
+        code = _lib.OUT_BF16 if out_dtype == torch.bfloat16 else _lib.OUT_F32
+        if isinstance(clip_offsets, torch.Tensor) and clip_offsets.is_cuda:
+            offs = clip_offsets.contiguous().to(torch.int64)
+            n_clips = offs.numel() - 1
+            if n_clips < 0:
+                raise ValueError("clip_offsets must hold at least one entry")
+            out = torch.empty((n_clips, self.output_dim), device=wave.device, dtype=out_dtype)
+            with torch.cuda.device(wave.device):
+                _lib.check(self._lib.radad_embed_forward_dev(self._h, wave.data_ptr(), offs.data_ptr(), n_clips, wave.numel(),
+                                                             out.data_ptr(), code, _lib.stream_ptr(wave.device)),
+                           "radad_embed_forward_dev")
+            return out
         offs = np.ascontiguousarray(np.asarray(clip_offsets, np.int64))
         n_clips = len(offs) - 1
         if n_clips < 0 or (n_clips >= 0 and (offs[0] < 0 or offs[-1] > wave.numel())):
             raise ValueError("clip_offsets outside the wave buffer")
-        out = torch.empty((n_clips, self.output_dim), device=wave.device, dtype=torch.float32)
+        out = torch.empty((n_clips, self.output_dim), device=wave.device, dtype=out_dtype)
         with torch.cuda.device(wave.device):
-            _lib.check(self._lib.radad_embed_forward(self._h, wave.data_ptr(), offs.ctypes.data_as(_lib.c_i64p),
-                                                     n_clips, out.data_ptr(), _lib.stream_ptr(wave.device)),
+            _lib.check(self._lib.radad_embed_forward_ex(self._h, wave.data_ptr(), offs.ctypes.data_as(_lib.c_i64p),
+                                                        n_clips, out.data_ptr(), code, _lib.stream_ptr(wave.device)),
                        "radad_embed_forward")
         return out
 

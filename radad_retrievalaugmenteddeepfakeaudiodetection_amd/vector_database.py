@@ -9,7 +9,7 @@ What callers of the reference rely on and still find here:
     used at vector_database.py:124,138,151,169,181 and pipeline.py:465,503).
 Index types: 'L2' -> squared-L2 ascending; 'IP' -> inner product descending, with rows and queries
 L2-normalised first when config.normalize_for_ip (default True) i.e. cosine (vector_database.py:61-64,97,100-105).
-'IVF' (vector_database.py:65-70) is not built: brute force is the path this package accelerates.
+'IVF' (vector_database.py:65-70) -> HipIVFFlatIndex (k-means coarse quantiser + list scan, csrc/ivf.inc; k <= 26).
 Device-resident variants (`search_device`, `reconstruct_batch`) let the pipeline skip the D2H/H2D hops.
 """
 import ctypes as C
@@ -139,20 +139,22 @@ class HipFlatIndex:
             _lib.check(self._lib.radad_knn_add(self._h, x.data_ptr(), x.shape[0], _lib.stream_ptr(x.device)), "radad_knn_add")
 
     def search_device(self, q, k: int, return_f64: bool = False):
-        """q [nq, d] CUDA tensor -> (D f32 [nq,k], I i64 [nq,k]) on the device; with return_f64 also the float64
-        distances the ranking was made on (used by the sharded merge)."""
+        """q [nq, d] CUDA tensor (float32, or bfloat16 = BASELINE config 5's bf16 embeddings, handed to the library as
+        they are) -> (D f32 [nq,k], I i64 [nq,k]) on the device; with return_f64 also the float64 distances the ranking
+        was made on (used by the sharded merge)."""
         import torch
         _lib.require_cuda(q, "q")
-        q = q.contiguous().float()
+        bf16 = q.dtype == torch.bfloat16
+        q = q.contiguous() if bf16 else q.contiguous().float()
         if q.dim() != 2 or q.shape[1] != self.d:
             raise ValueError(f"search expects [nq, {self.d}], got {tuple(q.shape)}")
         D = torch.empty((q.shape[0], k), device=q.device, dtype=torch.float32)
         I = torch.empty((q.shape[0], k), device=q.device, dtype=torch.int64)
         K64 = torch.empty((q.shape[0], k), device=q.device, dtype=torch.float64) if return_f64 else None
         with torch.cuda.device(q.device):
-            _lib.check(self._lib.radad_knn_search_f64(self._h, q.data_ptr(), q.shape[0], int(k), D.data_ptr(), I.data_ptr(),
-                                                      K64.data_ptr() if return_f64 else None, _lib.stream_ptr(q.device)),
-                       "radad_knn_search")
+            _lib.check(self._lib.radad_knn_search_ex(self._h, q.data_ptr(), _lib.Q_BF16 if bf16 else _lib.Q_F32, q.shape[0], int(k),
+                                                     D.data_ptr(), I.data_ptr(), K64.data_ptr() if return_f64 else None,
+                                                     _lib.stream_ptr(q.device)), "radad_knn_search")
         return (D, I, K64) if return_f64 else (D, I)
 
     def reconstruct_batch(self, idx):
@@ -294,8 +296,12 @@ class HipIVFFlatIndex:
 
     add_device = add
 
+    MAX_K = 26      # csrc/ivf.inc: k + 6 candidates per (query, list) in 32-entry register lists
+
     def search_device(self, q, k: int):
         import torch
+        if k > self.MAX_K:      # faiss accepts k up to 2048; refusing loudly beats the silent empty result a swallowed error gives
+            raise ValueError(f"HipIVFFlatIndex supports k <= {self.MAX_K} (asked for {k}); use a flat index for larger k")
         q = self._to_dev(q)
         D = torch.empty((q.shape[0], k), device=q.device, dtype=torch.float32)
         I = torch.empty((q.shape[0], k), device=q.device, dtype=torch.int64)
@@ -337,6 +343,7 @@ class VectorDatabase:
         os.makedirs(config.vector_db_path, exist_ok=True)
         self._cosine = False
         self._tags_host: List[int] = []      # path_tag of every stored row (device copy built lazily)
+        self._tag_names: Dict[int, str] = {}  # tag -> basename, to assert the tags are collision-free
         self._tags_dev = None
         self._labels_dev = None
         import torch
@@ -383,13 +390,21 @@ class VectorDatabase:
         added = 0
         for start in range(0, total, batch_size):
             end = min(start + batch_size, total)
+            # the 63-bit tags stand in for the basename strings the reference compares (pipeline.py:495-502): two distinct
+            # basenames must never share one.  Checked before anything is added (a collision is a hard error, not a skipped batch).
+            batch_tags = []
+            for p_ in paths[start:end]:
+                t_, b_ = path_tag(p_), os.path.basename(p_)
+                if self._tag_names.setdefault(t_, b_) != b_:
+                    raise RuntimeError(f"path_tag collision between {self._tag_names[t_]!r} and {b_!r}")
+                batch_tags.append(t_)
             try:
                 if is_dev:
                     self.index.add_device(vectors[start:end])
                 else:
                     self.index.add(vectors[start:end])     # normalisation for cosine happens in the add kernel
                 added += end - start
-                self._tags_host.extend(path_tag(p) for p in paths[start:end])
+                self._tags_host.extend(batch_tags)
                 self._tags_dev = self._labels_dev = None
                 self.vector_paths.extend(paths[start:end])
                 self.vector_labels.extend(labels[start:end])
@@ -440,7 +455,12 @@ class VectorDatabase:
         import torch
         if self._tags_dev is None or self._tags_dev.numel() != len(self.vector_paths):
             if len(self._tags_host) != len(self.vector_paths):          # e.g. after load()
-                self._tags_host = [path_tag(p) for p in self.vector_paths]
+                self._tags_host, self._tag_names = [], {}
+                for p_ in self.vector_paths:
+                    t_, b_ = path_tag(p_), os.path.basename(p_)
+                    if self._tag_names.setdefault(t_, b_) != b_:
+                        raise RuntimeError(f"path_tag collision between {self._tag_names[t_]!r} and {b_!r}")
+                    self._tags_host.append(t_)
             self._tags_dev = torch.tensor(self._tags_host, dtype=torch.int64, device=torch.device("cuda", self.device_id))
         return self._tags_dev
 
@@ -516,17 +536,21 @@ class VectorDatabase:
                 raise ValueError("sharded load is only available for native flat snapshots")
             if magic[:2] == b"PK":                      # numpy .npz: an IVF store written by save() above
                 z = np.load(self.db_path)
-                self.create_index(int(z["centroids"].shape[1]))
-                if not isinstance(self.index, HipIVFFlatIndex) or self.index.nlist != z["centroids"].shape[0]:
+                centroids, rows = z["centroids"], z["rows"]        # NpzFile re-reads an array on every access: read once
+                self.create_index(int(centroids.shape[1]))
+                if not isinstance(self.index, HipIVFFlatIndex) or self.index.nlist != centroids.shape[0]:
                     raise ValueError("saved IVF store does not match config (index type / ivf_nlist)")
-                self.index.set_centroids(z["centroids"])
-                for s0 in range(0, len(z["rows"]), 1 << 18):
-                    self.index.add(z["rows"][s0:s0 + (1 << 18)])
+                self.index.set_centroids(centroids)
+                for s0 in range(0, len(rows), 1 << 18):
+                    self.index.add(rows[s0:s0 + (1 << 18)])
             elif magic[:4] in (b"IxF2", b"IxFI"):
                 # a store written by the reference itself (faiss.write_index).  For cosine the reference had normalised
                 # the rows before adding them (vector_database.py:118); adding them again re-normalises unit rows, which
                 # changes them by at most one ulp.
-                _, d, rows = read_faiss_flat(self.db_path)
+                file_metric, d, rows = read_faiss_flat(self.db_path)
+                want = self.config.vector_db_index_type.upper()
+                if want in ("L2", "IP") and want != file_metric:     # faiss.read_index keeps the file's metric; so do we
+                    raise ValueError(f"{self.db_path} holds a faiss Index{file_metric} store but config asks for {want}")
                 self.create_index(d)
                 for s0 in range(0, len(rows), 1 << 18):
                     self.index.add(rows[s0:s0 + (1 << 18)])

@@ -1,0 +1,255 @@
+"""GPU parity of the certified scan (csrc/knn_hi.inc + k_merge_refine + k_exact_scan): the single-product f16 filter must
+return the exact float64 brute-force result on data built to defeat a low-precision filter -- by certificate where the
+candidate buffer suffices, through the exact kernel where it does not -- and BASELINE config 4 / 5 per-rank shapes."""
+import numpy as np
+import pytest
+
+from oracle import radad_oracle as O
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _index(metric, dim, f16=False, id_base=0):
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    m = {"L2": _lib.METRIC_L2, "IP": _lib.METRIC_IP, "COSINE": _lib.METRIC_COSINE}[metric]
+    return HipFlatIndex(dim, m, 0, id_base, store_f16=f16)
+
+
+def _stored(idx, n, gpu):
+    import torch
+    out = []
+    for r0 in range(0, n, 1 << 17):
+        out.append(idx.reconstruct_batch(torch.arange(r0, min(n, r0 + (1 << 17)), device=gpu)).cpu().numpy())
+    return np.concatenate(out)
+
+
+def _unit(x):
+    x = x.astype(np.float64)
+    return x / np.sqrt((x ** 2).sum(1))[:, None]
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "L2"])
+def test_near_ties_around_rank_k_pass_by_certificate(gpu, metric):
+    """24 rows whose scores differ by ~1e-7 (below 2^-22 of |q||y|) straddle rank k = 10 of query 5: an fp32 filter cannot
+    order them, the f16 filter even less; the float64 re-rank of everything within 2 eps must, WITHOUT the exact kernel."""
+    n, nq, dim, k = 40000, 64, 128, 10
+    db = synth.rows(0, n, dim, 7001)
+    q = synth.rows(0, nq, dim, 7002)
+    j = 5
+    for t in range(4):                                   # 4 clear winners
+        db[1000 + 977 * t] = q[j] + np.float32(0.01 * (t + 1)) * synth.rows(t, 1, dim, 7003)[0]
+    base = q[j] + np.float32(0.08) * synth.rows(99, 1, dim, 7003)[0]
+    for t in range(24):                                  # 24 near-ties spread over the store
+        row = base.copy()
+        row[t % dim] += np.float32(1e-6 * (t + 1))       # score differences ~1e-7
+        db[2000 + 1531 * t] = row
+    idx = _index(metric, dim)
+    idx.add(db)
+    D, I = idx.search(q, k)
+    info = idx.last_launch()
+    assert info["block_threads"] == 512
+    stored = _stored(idx, n, gpu)
+    if metric == "COSINE":
+        od, oi = O.knn(stored, _unit(q), k, "IP")
+    else:
+        od, oi = O.knn(stored, q, k, "L2")
+    assert O.rank_gaps(od).min() > 0
+    np.testing.assert_array_equal(I, oi)
+    assert info["rechecked_queries"] == 0, info
+    assert set(I[j][:4]) == {1000 + 977 * t for t in range(4)}
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "L2"])
+@pytest.mark.parametrize("f16", [False, True])
+def test_duplicates_and_dense_ties_take_the_exact_kernel(gpu, metric, f16):
+    """(a) 100 exact copies of one row inside ONE chunk (its 16-entry list is used up), (b) 300 near-ties spread over the
+    store (more than the candidate buffer holds): neither query can be certified; the exact float64 kernel must return
+    the brute-force result, ties to the lower id.  Every other query must still be certified."""
+    n, nq, dim, k = 50000, 80, 64, 15
+    db = synth.rows(0, n, dim, 7101)
+    q = synth.rows(0, nq, dim, 7102)
+    dup = q[7] + np.float32(0.05) * synth.rows(0, 1, dim, 7103)[0]
+    db[20000:20100] = dup                                # (a)
+    near = q[33] + np.float32(0.05) * synth.rows(1, 1, dim, 7103)[0]
+    for t in range(300):                                 # (b)
+        row = near.copy()
+        row[t % dim] += np.float32(3e-4 * ((t * 7) % 11 - 5))
+        db[(t * 163 + 11) % n] = row
+    idx = _index(metric, dim, f16=f16)
+    idx.add(db)
+    D, I = idx.search(q, k)
+    info = idx.last_launch()
+    stored = _stored(idx, n, gpu)
+    if metric == "COSINE":
+        qn = np.empty_like(q)
+        import torch
+        from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+        qt = torch.from_numpy(q).to(gpu); qo = torch.empty_like(qt)
+        _lib.check(_lib.load().radad_rownorm(qt.data_ptr(), qo.data_ptr(), nq, dim, 0, _lib.stream_ptr(gpu)))
+        od, oi = O.knn(stored, qo.cpu().numpy(), k, "IP")
+    else:
+        od, oi = O.knn(stored, q, k, "L2")
+    np.testing.assert_array_equal(I, oi)
+    np.testing.assert_allclose(D, od, rtol=1e-6, atol=1e-6)
+    assert list(I[7]) == list(range(20000, 20000 + k))   # exact ties: lower ids first
+    assert 2 <= info["rechecked_queries"] <= 6, info
+
+
+def test_bf16_queries_on_fp16_store(gpu):
+    """BASELINE config 5 in small: fp16 store + bfloat16 queries.  The library decodes bf16 exactly, so the result equals
+    the search with the same values handed over as fp32, and the float64 oracle over the decoded operands."""
+    import torch
+    n, nq, dim, k = 60000, 300, 256, 10
+    db = synth.rows(0, n, dim, 7201)
+    q = synth.rows(0, nq, dim, 7202)
+    for j in range(nq):
+        db[(j * 193 + 7) % n] = q[j] + np.float32(0.1) * synth.rows(j, 1, dim, 7203)[0]
+    idx = _index("COSINE", dim, f16=True)
+    idx.add(db)
+    qb = torch.from_numpy(q).to(gpu).to(torch.bfloat16)
+    D, I = idx.search_device(qb, k)
+    D2, I2 = idx.search_device(qb.float(), k)
+    assert torch.equal(I, I2) and torch.equal(D, D2)
+    stored = _stored(idx, n, gpu)
+    od, oi = O.knn(stored, _unit(qb.float().cpu().numpy()), k, "IP")
+    np.testing.assert_array_equal(I.cpu().numpy(), oi)
+    np.testing.assert_allclose(D.cpu().numpy(), od, atol=1e-6)
+    assert idx.last_launch()["block_threads"] == 512
+    # what the reduced precision costs against the full-precision pipeline (fp32 rows, fp32 queries): reported, loosely bounded
+    full = _index("COSINE", dim)
+    full.add(db)
+    _, If = full.search(q, k)
+    recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(I.cpu().numpy(), If)])
+    print(f"recall@{k} of bf16 queries x fp16 store vs fp32: {recall:.4f}")
+    assert recall > 0.9
+
+
+def test_embed_device_plan_and_bf16_output(gpu):
+    """radad_embed_forward_dev: the segment plan built on the device (k_build_plan) gives bit-identical embeddings to the
+    host-offset path on a ragged batch (segmenter.py:25-39: short clips padded, tails dropped); bf16 output is the
+    round-to-nearest-even of the fp32 output."""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    cfg = R.Config()
+    cfg.update(device=gpu, tpp_levels=[1, 2], feature_dim=64)
+    fe = R.MelProjectionFeatureExtractor(cfg)
+    lens = [100, 16000, 31999, 32000, 48000, 64000, 70001, 80000, 47999, 200000, 32001, 5]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    wave = torch.from_numpy(synth.audio(0, 1, int(offs[-1]), 77)[0]).to(gpu)
+    a = fe.embed_clips(wave, offs)
+    b = fe.embed_clips(wave, torch.from_numpy(offs).to(gpu))
+    assert torch.equal(a, b)
+    c = fe.embed_clips(wave, torch.from_numpy(offs).to(gpu), out_dtype=torch.bfloat16)
+    d = fe.embed_clips(wave, offs, out_dtype=torch.bfloat16)
+    assert c.dtype == torch.bfloat16 and torch.equal(c, a.to(torch.bfloat16)) and torch.equal(c, d)
+    # uniform batch (one workgroup per clip) with bf16 output, and a second, different set of offsets right behind the first
+    offs2 = np.arange(5, dtype=np.int64) * 64000
+    w2 = wave[:4 * 64000]
+    e = fe.embed_clips(w2, offs2)
+    f = fe.embed_clips(w2, torch.from_numpy(offs2).to(gpu))
+    g = fe.embed_clips(w2, offs2, out_dtype=torch.bfloat16)
+    assert torch.equal(e, f) and torch.equal(g, e.to(torch.bfloat16))
+    ref = O.embed_clips([wave[offs[i]:offs[i + 1]].cpu().numpy() for i in range(4)], fe.segment_length, fe.hop_length,
+                        fe.proj_w, fe.proj_b, levels=(1, 2), mode=cfg.tpp_pooling_type)
+    assert np.abs(a[:4].cpu().numpy() - ref).max() < 1e-4
+
+
+def _sample_check(knn_oracle_lib, stored, qn, I, K64, k, metric, id_base, sample):
+    from conftest import c_knn
+    od, oi = c_knn(knn_oracle_lib, stored, qn[sample], k, metric, id_base)
+    np.testing.assert_array_equal(I[sample], oi)
+    np.testing.assert_allclose(K64[sample], od, rtol=0, atol=1e-9)
+
+
+def test_config4_per_rank_shape(gpu, knn_oracle_lib):
+    """BASELINE config 4 as one rank of eight sees it: a 1.25 M x 512 fp32 shard with id_base != 0, all 10 240 queries,
+    k = 10 and 15; C oracle on a 48-query sample; two further shards merged on the float64 keys == the unsharded search."""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import hip_merge
+    lib = _lib.load()
+    n, dim, nq, base = 1_250_000, 512, 10_240, 3_750_000
+    rows = torch.empty((n, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(rows.data_ptr(), base, n, dim, 4321, 0, _lib.stream_ptr(gpu)))
+    q = torch.empty((nq, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(q.data_ptr(), 0, nq, dim, 977, 0, _lib.stream_ptr(gpu)))
+    planted = (torch.arange(nq, device=gpu) * 113 + 29) % n
+    rows[planted] = q + 0.05 * rows[:nq]
+    idx = HipFlatIndex(dim, _lib.METRIC_COSINE, 0, id_base=base)
+    idx.add_device(rows)
+    qn = torch.empty_like(q)
+    _lib.check(lib.radad_rownorm(q.data_ptr(), qn.data_ptr(), nq, dim, 0, _lib.stream_ptr(gpu)))
+    stored = torch.empty_like(rows)
+    _lib.check(lib.radad_rownorm(rows.data_ptr(), stored.data_ptr(), n, dim, 0, _lib.stream_ptr(gpu)))
+    stored_h = stored.cpu().numpy()
+    del stored
+    sample = np.arange(0, nq, nq // 48)[:48]
+    for k in (10, 15):
+        D, I, K64 = idx.search_device(q, k, return_f64=True)
+        info = idx.last_launch()
+        assert info["block_threads"] == 512 and info["rechecked_queries"] <= nq // 100, info
+        assert bool((D[:, :-1] >= D[:, 1:]).all()) and bool((I >= base).all()) and bool((I < base + n).all())
+        assert bool((I[:, 0] == planted + base).all())
+        _sample_check(knn_oracle_lib, stored_h, qn.cpu().numpy(), I.cpu().numpy(), K64.cpu().numpy(), k, "IP", base, sample)
+    # the same rows as three shards (uneven) merged on the float64 keys
+    k = 15
+    cuts = [0, 400_000, 830_001, n]
+    keys, ids = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        sh = HipFlatIndex(dim, _lib.METRIC_COSINE, 0, id_base=base + a)
+        sh.add_device(rows[a:b])
+        _, i_, k_ = sh.search_device(q, k, return_f64=True)
+        keys.append(k_); ids.append(i_)
+        del sh
+    md, mi = hip_merge(_lib.METRIC_COSINE, torch.stack(keys), torch.stack(ids), k)
+    assert torch.equal(mi, I) and torch.equal(md, D)
+
+
+def test_config5_per_rank_shape(gpu, knn_oracle_lib):
+    """BASELINE config 5 as one rank of eight sees it: a 6.25 M x 256 fp16 shard, 10 240 bfloat16 queries, fp32
+    accumulate, float64 re-rank over the decoded operands; C oracle on a 32-query sample; recall@10 against the fp32
+    pipeline (fp32 rows, fp32 queries) on that sample."""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    lib = _lib.load()
+    n, dim, nq, k, base = 6_250_000, 256, 10_240, 10, 12_500_000
+    idx = HipFlatIndex(dim, _lib.METRIC_COSINE, 0, id_base=base, store_f16=True)
+    idx.reserve(n)
+    q = torch.empty((nq, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(q.data_ptr(), 0, nq, dim, 977, 0, _lib.stream_ptr(gpu)))
+    planted = (torch.arange(nq, device=gpu) * 601 + 5) % n
+    step = 1 << 20
+    raw_h = np.empty((n, dim), np.float32)               # the fp32 rows, for the full-precision comparison
+    for r0 in range(0, n, step):
+        m = min(step, n - r0)
+        rows = torch.empty((m, dim), device=gpu)
+        _lib.check(lib.radad_synth_rows(rows.data_ptr(), base + r0, m, dim, 4321, 0, _lib.stream_ptr(gpu)))
+        sel = (planted >= r0) & (planted < r0 + m)
+        rows[planted[sel] - r0] = q[sel] + 0.05 * rows[:int(sel.sum())]
+        idx.add_device(rows)
+        raw_h[r0:r0 + m] = rows.cpu().numpy()
+    assert idx.ntotal == n
+    qb = q.to(torch.bfloat16)
+    D, I, K64 = idx.search_device(qb, k, return_f64=True)
+    info = idx.last_launch()
+    assert info["block_threads"] == 512 and info["rechecked_queries"] <= nq // 100, info
+    assert bool((D[:, :-1] >= D[:, 1:]).all()) and bool((I >= base).all()) and bool((I < base + n).all())
+    assert bool((I[:, 0] == planted + base).all())
+    sample = np.arange(0, nq, nq // 32)[:32]
+    stored_h = np.empty((n, dim), np.float32)
+    for r0 in range(0, n, step):
+        ids = torch.arange(base + r0, base + min(n, r0 + step), device=gpu)
+        stored_h[r0:r0 + len(ids)] = idx.reconstruct_batch(ids).cpu().numpy()
+    qn = torch.empty_like(q)
+    qf = qb.float().contiguous()
+    _lib.check(lib.radad_rownorm(qf.data_ptr(), qn.data_ptr(), nq, dim, 0, _lib.stream_ptr(gpu)))
+    _sample_check(knn_oracle_lib, stored_h, qn.cpu().numpy(), I.cpu().numpy(), K64.cpu().numpy(), k, "IP", base, sample)
+    # recall against full precision: cosine over the fp32 rows with the fp32 queries (fp32 BLAS is plenty for a recall figure)
+    rn = np.sqrt((raw_h.astype(np.float64) ** 2).sum(1)).astype(np.float32)
+    cos = (raw_h @ q[sample].cpu().numpy().T) / rn[:, None]
+    part = np.argpartition(-cos, k, axis=0)[:k]
+    top = np.take_along_axis(part, np.argsort(-np.take_along_axis(cos, part, 0), axis=0), 0).T + base
+    recall = np.mean([len(set(a) & set(b)) / k for a, b in zip(I.cpu().numpy()[sample], top)])
+    print(f"config 5 per-rank recall@{k} (bf16 queries x fp16 store vs fp32): {recall:.4f}")
+    assert recall > 0.9
