@@ -9,8 +9,9 @@
  *     and the call returns without synchronising unless the comment says otherwise.
  *   - every function returns 0 on success and a negative RADAD_E* code on failure; the message for the
  *     calling thread is available from radad_last_error().
- *   - handles are opaque.  A handle may be searched/reconstructed from several threads (calls are
- *     serialised internally); add/load/destroy must not race with anything else.
+ *   - handles are opaque.  A handle may be searched/reconstructed from several threads (host calls are serialised by a
+ *     mutex, the device work of consecutive searches by an event: they share one workspace); add/load/destroy must
+ *     not race with anything else.
  *
  * Each group cites the reference interface (file:line under the RADAD repository) it replaces.
  */
@@ -92,10 +93,15 @@ int radad_knn_add_host(radad_knn_t h, const float* rows_host, int64_t n);
 int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev,
                      int64_t* out_idx_dev, void* stream);
 /* same search, additionally returning the float64 distances the final ranking was made on
- * (out_key_dev [nq, k] double, may be NULL).  The fp32 MFMA scan only selects k + 6 candidates per query; they are
- * re-scored in float64 from the stored rows (L2 as sum (q-y)^2) and ordered by (float64 distance, id), so ids and
- * order are those of an exact brute force and out_dist is the correctly rounded distance.  Sharded searches merge
- * on these keys (radad_topk_merge_f64) so that no cross-shard pair is decided by fp32 rounding. */
+ * (out_key_dev [nq, k] double, may be NULL).  The MFMA scan is a filter with a measured error bound eps(q): every listed
+ * row whose scan score is within 2 eps of the k-th best is re-scored in float64 from the stored rows (L2 as sum (q-y)^2)
+ * and ordered by (float64 distance, id); a per-query certificate checks that no unlisted row can reach that threshold, and
+ * the queries it rejects are searched again by an exact float64 kernel (driven from the device, no host round trip).  For
+ * k <= 128 ids and order are therefore those of an exact float64 brute force, ties to the lower id, and out_dist is the
+ * correctly rounded distance; for larger k the k + 6 best scan candidates are re-ranked without a certificate.  Sharded
+ * searches merge on these keys (radad_topk_merge_f64) so that no cross-shard pair is decided by fp32 rounding.
+ * A handle may be searched from several threads and streams: calls are serialised by a mutex and each search's device
+ * work waits (event) for the previous one's, since they share the handle's workspace. */
 int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev,
                          int64_t* out_idx_dev, double* out_key_dev, void* stream);
 /* same with a choice of query type: RADAD_Q_BF16 = bfloat16 queries [nq, dim] (BASELINE config 5: bf16 embeddings,
@@ -125,10 +131,13 @@ int radad_knn_snapshot_info(const char* path, int* dim_out, int* metric_out, int
 /* seconds spent in the most recent search's kernels are NOT measured here; use HIP events on `stream`.
  * Query the launch geometry of the last search (for roofline accounting in bench.py). */
 int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, int* block_threads);
-/* k > 10 with more than 128 queries: the scan keeps 16 candidates per store chunk and the re-rank certifies per query
- * that no chunk's list was exhausted; queries that fail are searched again with full-length lists (same results as if
- * the whole batch had been).  Number of such queries in the most recent search (diagnostics). */
+/* Certificate of the most recent search (see radad_knn_search_f64): number of queries the float64 re-rank could NOT certify
+ * and that were therefore searched again by the exact float64 kernel (results are exact either way).  Synchronises with
+ * that search.  radad_knn_last_certificate additionally returns the batch size and stats6 = {rejected queries, sum over
+ * the batch of candidates re-scored in float64, rejections because: the candidate buffer was full, a chunk's list was used
+ * up, the scan's admission floor was above the threshold, the scan dropped a candidate}. */
 int radad_knn_last_recheck(radad_knn_t h, int* n_queries);
+int radad_knn_last_certificate(radad_knn_t h, int64_t* n_queries, int* stats6);
 
 /* HIP-event timing of the scan kernel (k_knn_f32) alone, on the stream each search is enqueued on:
  * enable -> every search records an event pair around the kernel launch (ring of 64); read synchronises on the

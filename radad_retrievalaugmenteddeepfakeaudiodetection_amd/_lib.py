@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libradad_hip.so")
+# RADAD_HIP_LIB: another build of the same library (tools/exp_*.py point it at libradad_hip_exp.so, the build with the
+# kernels' timing-ablation switches); the default is the in-tree product library
+LIB_PATH = os.environ.get("RADAD_HIP_LIB") or os.path.join(_HERE, "libradad_hip.so")
 
 RADAD_OK, RADAD_EINVAL, RADAD_EHIP, RADAD_ENOMEM, RADAD_EIO, RADAD_ESTATE = 0, -1, -2, -3, -4, -5
 METRIC_L2, METRIC_IP, METRIC_COSINE = 0, 1, 2
@@ -73,6 +75,7 @@ SIGNATURES = {
     "radad_knn_snapshot_info": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                           C.POINTER(C.c_int64)]),
     "radad_knn_last_recheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "radad_knn_last_certificate": (C.c_int, [C.c_void_p, c_i64p, C.POINTER(C.c_int)]),
     "radad_knn_last_launch": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "radad_knn_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "radad_knn_profile_read": (C.c_int, [C.c_void_p, c_f32p, C.c_int, C.POINTER(C.c_int)]),

@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <mutex>
 #include <new>
 #include <stdlib.h>
@@ -803,8 +804,8 @@ constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float2)
 // k_merge_lists<KeyT> (radad_topk_merge / _f64): plain P-way merge of final per-shard lists, no rescoring.
 constexpr int KNN_MARGIN = 6;            // spare entries of a (query, chunk) list on the fp32 tile kernels
 constexpr int KNN_CERT_EXTRA = 32;       // candidates beyond k the certified re-rank can take before it gives up, at least ...
-constexpr int KNN_CERT_CAP = 128;        // ... and this many in all: stores of near-duplicates (the benchmark plants 2048 rows
-                                         // within 2e-3 of every query) put ~50 rows within 2 eps of the k-th
+constexpr int KNN_CERT_CAP = 512;        // ... and this many in all: stores of near-duplicates (the benchmark plants 2048 rows
+                                         // within 2e-2 of every query) put hundreds of rows within 2 eps of the k-th
 constexpr int KNN_CERT_MAX_K = 128;      // largest k the certificate + exact kernel cover
 constexpr int KW_SAMPLE_BLOCKS = 1024;   // workgroups of the threshold pre-pass, at most (4 waves of one-tile workgroups)
 constexpr int KW_SAMPLE_SPLITS = 64;     // one-tile splits of the threshold pre-pass (<= 16384 rows)
@@ -820,6 +821,8 @@ struct RefineParams {
     const int* qflag;         // optional [nq]: the scan dropped a candidate of this query
     int* flag_count;          // certified mode: [1] number of uncertified queries (atomicAdd) ...
     int* flag_sel;            // ... and their indices, in arrival order
+    int* stats;               // optional [5]: sum of candidates re-scored, queries rejected for: buffer full / list used up /
+                              // floor above tau / dropped by the scan
     int64_t nq;
     const void* db;           // stored rows (normalised for cosine); fp16 when db_f16
     int db_f16;
@@ -838,21 +841,26 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
     const int wave = threadIdx.x >> 6;
     const int64_t q = (int64_t)blockIdx.x * p.waves_per_block + wave;
     if (wave >= p.waves_per_block || q >= p.nq) return;
-    // per-wave LDS: double key[cap] | int id[cap] | int pos[n_parts]
-    const size_t per_wave = (size_t)p.cap * 12 + (size_t)p.n_parts * 4;
+    // per-wave LDS: double key[cap] | int id[cap] | int pos[n_parts] | int end[n_parts]
+    const size_t per_wave = (size_t)p.cap * 12 + (size_t)p.n_parts * 8;
     char* base = smem_m + (((size_t)wave * per_wave + 15) & ~(size_t)15) + (size_t)wave * 16;
     double* c_key = reinterpret_cast<double*>(base);
     int* c_id = reinterpret_cast<int*>(base + (size_t)p.cap * 8);
     int* s_pos = c_id + p.cap;
+    int* s_end = s_pos + p.n_parts;
     for (int i = lane; i < p.n_parts; i += 64) s_pos[i] = 0;
 
-    // 1) candidates in descending scan order (a wave only touches its own LDS slice: program order suffices)
+    // 1) candidates (a wave only touches its own LDS slice: program order suffices).
+    //    First the k best by scan score, by k rounds of "wave-wide best list head, the winning list advances" (legacy mode:
+    //    `cap` rounds, and that is all); that fixes a_k and tau = a_k - 2 eps.  Then every lane walks on through its own
+    //    lists and appends the entries >= tau (sorted lists: stop at the first one below) -- no more rounds, whatever the
+    //    number of near-ties.
     const bool cert = p.eps != nullptr;
     const float two_eps = cert ? 2.f * p.eps[q] : 0.f;
     float tau = -INFINITY;                   // defined once k candidates are in
     int nsel = 0;
-    bool more = false;                       // a head >= tau was left behind because the buffer is full
-    for (;;) {
+    const int rounds = cert ? min(p.k, p.cap) : p.cap;
+    for (int o = 0; o < rounds; ++o) {
         float bs = -INFINITY;
         int bi = IDX_SENTINEL, bp = -1;
         for (int part = lane; part < p.n_parts; part += 64) {
@@ -872,28 +880,69 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
             if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
         }
         if (bp < 0) break;                                   // every list exhausted (wave-uniform)
-        if (cert && nsel >= p.k && bs < tau) break;          // everything left is below tau
-        if (nsel >= p.cap) { more = cert; break; }
         if ((bp & 63) == lane) s_pos[bp] += 1;
         if (lane == 0) c_id[nsel] = bi;
         ++nsel;
         if (cert && nsel == p.k) tau = bs - two_eps;
     }
     if (cert) {
-        // a list the selection consumed completely -- and that was full -- may hide rows with a >= tau; everything else
-        // a list hides is below its next head, hence below tau
-        int bad = more ? 1 : 0;
+        int why = 0;                         // bit 0: candidate buffer full, 1: a full list used up, 2: admission floor above tau, 3: dropped
+        for (int part = lane; part < p.n_parts; part += 64) s_end[part] = s_pos[part];
+        if (nsel == p.k) {
+            // every lane walks on through its own lists: entries [s_pos, s_end) are >= tau (sorted lists: stop at the first below)
+            for (int part = lane; part < p.n_parts; part += 64) {
+                int pos = s_pos[part];
+                const int64_t lb = ((int64_t)q * p.n_parts + part) * p.part_len;
+                while (pos < p.part_len) {
+                    const int id = p.idx[lb + pos];
+                    if (id == IDX_SENTINEL || p.score[lb + pos] < tau) break;
+                    ++pos;
+                }
+                s_end[part] = pos;
+            }
+            // append them: 64 lists per sweep, slots by a prefix sum over the lanes
+            for (int p0 = 0; p0 < p.n_parts; p0 += 64) {
+                const int part = p0 + lane;
+                const int first = part < p.n_parts ? s_pos[part] : 0;
+                const int cnt = part < p.n_parts ? s_end[part] - first : 0;
+                int incl = cnt;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const int t = __shfl_up(incl, o, 64);
+                    if (lane >= o) incl += t;
+                }
+                const int total = __shfl(incl, 63, 64);
+                const int base_slot = nsel + incl - cnt;
+                if (cnt > 0) {
+                    const int64_t lb = ((int64_t)q * p.n_parts + part) * p.part_len;
+                    for (int j = 0; j < cnt; ++j)
+                        if (base_slot + j < p.cap) c_id[base_slot + j] = p.idx[lb + first + j];
+                }
+                nsel += total;
+            }
+            if (nsel > p.cap) { nsel = p.cap; why |= 1; }
+        }
+        // a full list whose entries are ALL >= tau may hide more such rows; everything else a list hides is below its
+        // first entry < tau (or, for a list that never filled up, below the admission floor)
+        int bad = 0;
         for (int part = lane; part < p.n_parts; part += 64)
-            if (s_pos[part] >= p.part_len &&
+            if (s_end[part] >= p.part_len &&
                 p.idx[((int64_t)q * p.n_parts + part) * p.part_len + p.part_len - 1] != IDX_SENTINEL) bad = 1;
 #pragma unroll
         for (int ofs = 32; ofs > 0; ofs >>= 1) bad |= __shfl_xor(bad, ofs, 64);
+        if (bad) why |= 2;
         if (p.thr_init) {
             const float fl = p.thr_init[q];
-            if (fl > -INFINITY && !(nsel >= p.k && fl <= tau)) bad = 1;      // rows below the floor are unlisted
+            if (fl > -INFINITY && !(nsel >= p.k && fl <= tau)) why |= 4;      // rows below the floor are unlisted
         }
-        if (p.qflag && p.qflag[q]) bad = 1;
-        if (bad && lane == 0) p.flag_sel[atomicAdd(p.flag_count, 1)] = (int)q;
+        if (p.qflag && p.qflag[q]) why |= 8;
+        if (lane == 0) {
+            if (why) p.flag_sel[atomicAdd(p.flag_count, 1)] = (int)q;
+            if (p.stats) {
+                atomicAdd(&p.stats[0], nsel);
+                for (int b2 = 0; b2 < 4; ++b2) if (why & (1 << b2)) atomicAdd(&p.stats[1 + b2], 1);
+            }
+        }
     }
     // 2) float64 re-score of the candidates
     const float* qrow = p.q + q * p.dim;
@@ -1308,7 +1357,7 @@ struct radad_knn_s {
     int64_t stat_rows = 0;
     // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
     // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
-    int* host_count = nullptr;   // pinned [1]
+    int* host_count = nullptr;   // pinned [8]: rejected queries, sum of candidates, rejections by reason x 4
     hipEvent_t ev_count = nullptr, ev_done = nullptr;
     bool count_pending = false, done_recorded = false;
     int64_t count_nq = 0;        // batch size of the search host_count belongs to
@@ -1452,14 +1501,14 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
     { const char* e = getenv("RADAD_KNN_HI"); h->hi_off = (e && atoi(e) == 0) ? 1 : 0; }
     {
         DeviceGuard g(device);
-        if (hipHostMalloc(reinterpret_cast<void**>(&h->host_count), sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->host_count), 8 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_count, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess) {
             radad_set_error("radad_knn_create: pinned counter / events could not be created");
             radad_knn_destroy(h);
             return RADAD_EHIP;
         }
-        *h->host_count = 0;
+        memset(h->host_count, 0, 8 * sizeof(int));
     }
     *out = h;
     return RADAD_OK;
@@ -1752,6 +1801,10 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         wp.n = h->ntotal; wp.nq = (int)nq; wp.row_bytes = h->dim * 2; wp.l2 = l2;
         wp.n_qtiles = n_qtiles; wp.n_splits = n_splits; wp.chunk_rows = chunk_rows; wp.part_score = ps; wp.part_idx = pi;
         wp.thr_init = nullptr; wp.qflag = qflag;
+        wp.debug = 0;
+#ifdef RADAD_DEBUG_HOOKS        // timing experiments only (make exp); never in the shipped library
+        { const char* dbg = getenv("RADAD_DEBUG_KNN"); wp.debug = dbg ? atoi(dbg) : 0; }
+#endif
         const int rsc = l2 ? 2 : (wp.rscale ? 1 : 0);
         const size_t lds = knn_hi_lds_bytes();
         const void* fns[3] = {reinterpret_cast<const void*>(k_knn_hi<0>), reinterpret_cast<const void*>(k_knn_hi<1>),
@@ -1833,7 +1886,8 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     m.flag_count = flag_count; m.flag_sel = flag_sel;
     m.db = h->rows; m.db_f16 = h->f16; m.q = q_use; m.id_map = nullptr; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
     m.out_key = out_key_dev;
-    const size_t per_wave = (((size_t)cap * 12 + (size_t)n_splits * 4 + 15) & ~(size_t)15) + 16;
+    m.stats = cert ? flag_count + 1 : nullptr;
+    const size_t per_wave = (((size_t)cap * 12 + (size_t)n_splits * 8 + 15) & ~(size_t)15) + 16;
     m.waves_per_block = (int)std::max<size_t>(1, std::min<size_t>(4, (60 * 1024) / per_wave));
     hipLaunchKernelGGL(k_merge_refine, dim3((unsigned)ceil_div64(nq, m.waves_per_block)), dim3(256),
                        per_wave * m.waves_per_block + 64, st, m);
@@ -1853,7 +1907,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         hipLaunchKernelGGL(k_exact_scan, dim3(KX_SLICES, KX_GROUPS_Y), dim3(KX_THREADS), xlds, st, x);
         hipLaunchKernelGGL(k_exact_merge, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, x);
         RADAD_HIP_CHECK(hipGetLastError());
-        RADAD_HIP_CHECK(hipMemcpyAsync(h->host_count, flag_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        RADAD_HIP_CHECK(hipMemcpyAsync(h->host_count, flag_count, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
         RADAD_HIP_CHECK(hipEventRecord(h->ev_count, st));
         h->count_pending = true;
         h->count_nq = nq;
@@ -1955,6 +2009,16 @@ int radad_knn_last_recheck(radad_knn_t h, int* n_queries) {
     DeviceGuard g(h->device);
     if (h->count_pending) RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count));
     *n_queries = h->host_count ? *h->host_count : 0;
+    return RADAD_OK;
+}
+
+int radad_knn_last_certificate(radad_knn_t h, int64_t* n_queries, int* stats6) {
+    RADAD_REQUIRE(h && stats6, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    if (h->count_pending) RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count));
+    for (int i = 0; i < 6; ++i) stats6[i] = h->host_count ? h->host_count[i] : 0;
+    if (n_queries) *n_queries = h->count_nq;
     return RADAD_OK;
 }
 

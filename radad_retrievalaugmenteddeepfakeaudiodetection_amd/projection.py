@@ -99,6 +99,58 @@ class ProjectionLayer(nn.Module):
         """projection.py:119-122."""
         return self.forward(torch.stack(input_embeddings_list).to(self.device))
 
+    @torch.no_grad()
+    def get_attention_weights(self, input_embeddings: torch.Tensor) -> torch.Tensor:
+        """projection.py:125-130: softmax over the K neighbours of  W2 tanh(W1 x + b1) + b2  -> [B, K, 1].
+        The two Linear layers run on radad_linear_forward (split-K MFMA GEMM with the tanh fused); the softmax over the
+        K (= 5) scores per row is a torch op on the [B, K] result."""
+        x = _lib.require_cuda(input_embeddings.to(self.device), "input_embeddings").detach().contiguous().float()
+        if x.dim() != 3 or x.shape[2] != self.input_dim:
+            raise ValueError(f"expected [B, K, {self.input_dim}], got {tuple(x.shape)}")
+        B, K, D = x.shape
+        lib = _lib.load()
+        H = self.hidden_dim
+
+        def linear(inp, lin, act, n_out, n_in):
+            rows = inp.shape[0]
+            w, b = lin.weight.detach().contiguous().float(), lin.bias.detach().contiguous().float()
+            out = torch.empty((rows, n_out), device=inp.device, dtype=torch.float32)
+            need = lib.radad_linear_workspace_bytes(rows, n_out, n_in)
+            ws = torch.empty(max(int(need), 1), dtype=torch.uint8, device=inp.device)
+            with torch.cuda.device(inp.device):
+                _lib.check(lib.radad_linear_forward(inp.data_ptr(), n_in, w.data_ptr(), n_in, b.data_ptr(), act, rows, n_out, n_in,
+                                                    out.data_ptr(), n_out, ws.data_ptr(), int(ws.numel()), inp.device.index,
+                                                    _lib.stream_ptr(inp.device)), "radad_linear_forward")
+            return out
+        hidden = linear(x.reshape(B * K, D), self.attention_score, 1, H, D)          # tanh fused
+        scores = linear(hidden, self.attention_final, 0, 1, H).reshape(B, K, 1)
+        return torch.softmax(scores, dim=1)
+
+    def memory_efficient_forward(self, input_embeddings: torch.Tensor, chunk_size: int = 32) -> torch.Tensor:
+        """projection.py:132-138: the forward in chunks of `chunk_size` rows (kept for callers; the HIP forward's workspace
+        is a few MB at any batch size, so chunking buys nothing here)."""
+        if input_embeddings.size(0) <= chunk_size:
+            return self.forward(input_embeddings)
+        return torch.cat([self.forward(input_embeddings[i:i + chunk_size]) for i in range(0, input_embeddings.size(0), chunk_size)], dim=0)
+
+    def profile_performance(self, input_shape: tuple, num_iterations: int = 100):
+        """projection.py:140-153: average wall time of a forward on random input (prints, and returns ms per iteration)."""
+        import time
+        dummy = torch.randn(input_shape, device=self.device)
+        was_training = self.training
+        self.eval()
+        for _ in range(10):
+            self.forward(dummy)
+        torch.cuda.synchronize(self.device)
+        t0 = time.time()
+        for _ in range(num_iterations):
+            self.forward(dummy)
+        torch.cuda.synchronize(self.device)
+        ms = (time.time() - t0) / max(1, num_iterations) * 1000
+        self.train(was_training)
+        print(f"Avg forward: {ms:.2f} ms/iter")
+        return ms
+
     def get_flops(self, input_shape: tuple) -> int:
         """projection.py:155-160."""
         B, K, D = input_shape

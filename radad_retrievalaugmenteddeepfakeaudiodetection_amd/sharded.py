@@ -51,27 +51,38 @@ class ShardedSearch:
     local_search(q [Q,D], k) -> (dist [Q,k], gid [Q,k]) must return GLOBAL ids (HipFlatIndex with id_base does);
     dist may be float64 (HipFlatIndex.search_device(..., return_f64=True)[2]) -- it is what gets merged.
     merge(metric, dists [G,Q,k], idxs [G,Q,k], k) -> ([Q,k],[Q,k]); defaults to the HIP merge kernel.
-    Every rank must call `search` with the same k (and the same number of local queries unless
-    `uneven=True`, which pads to the max).
+    Every rank must call `search` with the same k.  uneven=False (default): every rank passes the same number of local
+    queries.  uneven=True: the counts may differ (or be zero); one extra tiny all-gather of the counts per search, local
+    blocks are padded to the largest.
+    exchange: how the per-shard lists travel -- "all_to_all" (each rank receives only the lists of its own queries: 1/world
+    of an all-gather's traffic; RCCL and gloo both implement it) or "all_gather" (+ slice).  It is fixed HERE, identically on
+    every rank: a collective is never retried with a different primitive (a rank that failed alone would leave the others
+    inside the first one).
     """
 
-    def __init__(self, local_search: Callable, metric: int, group=None, merge: Optional[Callable] = None):
+    def __init__(self, local_search: Callable, metric: int, group=None, merge: Optional[Callable] = None,
+                 uneven: bool = False, exchange: str = "all_to_all"):
         import torch.distributed as dist
+        if exchange not in ("all_to_all", "all_gather"):
+            raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
         self.local_search = local_search
         self.metric = int(metric)
         self.group = group
         self.merge = merge or hip_merge
+        self.uneven = bool(uneven)
+        self.exchange = exchange
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # gloo moves host memory: device tensors are staged through the host (CPU tests; rehearsing ranks on one GPU)
+        self.staged = dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     def _all_gather(self, t):
-        """[n, ...] per rank -> [world*n, ...] (rank-major).  RCCL gathers device tensors in place; a gloo group
-        (CPU tests, or rehearsing several ranks on one GPU) stages through host memory."""
+        """[n, ...] per rank -> [world*n, ...] (rank-major)."""
         import torch
         import torch.distributed as dist
         t = t.contiguous()
         out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
-        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+        if t.is_cuda and self.staged:
             host = torch.empty(out.shape, dtype=t.dtype)
             dist.all_gather_into_tensor(host, t.cpu(), group=self.group)
             out.copy_(host)
@@ -81,42 +92,54 @@ class ShardedSearch:
 
     def _exchange(self, t, qr: int):
         """t [world*qr, k]: this shard's lists for ALL queries, rank-major -> [world, qr, k]: every shard's lists for THIS
-        rank's queries.  One all-to-all (each rank receives only the rows it merges: 1/world of an all-gather's traffic);
-        backends without it fall back to the all-gather and a slice."""
+        rank's queries."""
         import torch
         import torch.distributed as dist
         t = t.contiguous()
         k = t.shape[1]
-        try:
-            if t.is_cuda and dist.get_backend(self.group) == "gloo":
-                host_out = torch.empty((self.world * qr, k), dtype=t.dtype)
-                dist.all_to_all_single(host_out, t.cpu(), group=self.group)
-                return host_out.to(t.device).view(self.world, qr, k)
-            out = torch.empty((self.world * qr, k), device=t.device, dtype=t.dtype)
-            dist.all_to_all_single(out, t, group=self.group)
-            return out.view(self.world, qr, k)
-        except (RuntimeError, NotImplementedError):
-            Q = t.shape[0]
+        if self.exchange == "all_gather":
             sl = slice(self.rank * qr, (self.rank + 1) * qr)
-            return self._all_gather(t).view(self.world, Q, k)[:, sl].contiguous()
+            return self._all_gather(t).view(self.world, self.world * qr, k)[:, sl].contiguous()
+        if t.is_cuda and self.staged:
+            host_out = torch.empty((self.world * qr, k), dtype=t.dtype)
+            dist.all_to_all_single(host_out, t.cpu(), group=self.group)
+            return host_out.to(t.device).view(self.world, qr, k)
+        out = torch.empty((self.world * qr, k), device=t.device, dtype=t.dtype)
+        dist.all_to_all_single(out, t, group=self.group)
+        return out.view(self.world, qr, k)
 
     def gather_queries(self, q_local):
         return q_local if self.world == 1 else self._all_gather(q_local)
 
     def search(self, q_local, k: int, return_all: bool = False):
-        """q_local [Q_r, D] (same Q_r on every rank) -> this rank's rows of the merged result
-        ([Q_r,k] distances, [Q_r,k] global ids); `return_all` returns all Q rows instead."""
+        """q_local [Q_r, D] -> this rank's rows of the merged result ([Q_r,k] distances, [Q_r,k] global ids);
+        `return_all` returns the rows of all ranks' queries instead (rank-major; with uneven=True: padded blocks removed)."""
         import torch
-        import torch.distributed as dist
-        q_all = self.gather_queries(q_local)
-        d_loc, i_loc = self.local_search(q_all, k)
         if self.world == 1:
+            d_loc, i_loc = self.local_search(q_local, k)
             return d_loc.float(), i_loc
+        qr = q_local.shape[0]
+        counts = None
+        if self.uneven:
+            c = torch.tensor([qr], dtype=torch.int64, device=q_local.device)
+            counts = [int(x) for x in self._all_gather(c).cpu().tolist()]
+            qmax = max(max(counts), 1)
+            if qr < qmax:                                   # pad with copies of a zero query: results are dropped below
+                pad = torch.zeros((qmax - qr,) + tuple(q_local.shape[1:]), device=q_local.device, dtype=q_local.dtype)
+                q_local = torch.cat([q_local, pad])
+            qr_pad = qmax
+        else:
+            qr_pad = qr
+        q_all = self._all_gather(q_local)
+        d_loc, i_loc = self.local_search(q_all, k)
         Q = q_all.shape[0]
         if return_all:
-            # concatenated output form (accepted by both RCCL and gloo), viewed as [G, Q, k]
             d_all = self._all_gather(d_loc).view(self.world, Q, k)
             i_all = self._all_gather(i_loc).view(self.world, Q, k)
-            return self.merge(self.metric, d_all, i_all, k)
-        qr = q_local.shape[0]
-        return self.merge(self.metric, self._exchange(d_loc, qr), self._exchange(i_loc, qr), k)
+            md, mi = self.merge(self.metric, d_all, i_all, k)
+            if counts is not None:
+                keep = torch.cat([torch.arange(r * qr_pad, r * qr_pad + c) for r, c in enumerate(counts)]).to(md.device)
+                md, mi = md[keep], mi[keep]
+            return md, mi
+        md, mi = self.merge(self.metric, self._exchange(d_loc, qr_pad), self._exchange(i_loc, qr_pad), k)
+        return md[:qr], mi[:qr]

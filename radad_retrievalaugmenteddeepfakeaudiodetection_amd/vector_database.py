@@ -171,9 +171,12 @@ class HipFlatIndex:
     def last_launch(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         _lib.check(self._lib.radad_knn_last_launch(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        r = C.c_int()
-        _lib.check(self._lib.radad_knn_last_recheck(self._h, C.byref(r)))
-        return {"query_tiles": a.value, "db_splits": b.value, "block_threads": c.value, "rechecked_queries": r.value}
+        st, nq = (C.c_int * 6)(), C.c_int64()
+        _lib.check(self._lib.radad_knn_last_certificate(self._h, C.byref(nq), st))
+        return {"query_tiles": a.value, "db_splits": b.value, "block_threads": c.value, "rechecked_queries": st[0],
+                "certificate": {"queries": nq.value, "rejected": st[0], "candidates_rescored": st[1],
+                                "rejected_buffer_full": st[2], "rejected_list_used_up": st[3],
+                                "rejected_floor_above_threshold": st[4], "rejected_scan_dropped": st[5]}}
 
     def profile(self, enable: bool = True):
         """record HIP events around every scan-kernel launch (ring of 64)"""

@@ -327,3 +327,30 @@ def test_vector_database_sharded_load(gpu, tmp_path):
     Dm, Im = hip_merge(_lib.METRIC_COSINE, torch.stack(keys), torch.stack(ids), 5)
     assert torch.equal(Im, I0)
     np.testing.assert_allclose(Dm.cpu().numpy(), D0.cpu().numpy(), rtol=0, atol=1e-6)
+
+
+def test_projection_layer_extras(gpu):
+    """projection.py:125-153 mirrors: get_attention_weights == softmax_K(W2 tanh(W1 x + b1) + b2) in float64;
+    memory_efficient_forward == forward; profile_performance runs."""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    cfg = R.Config()
+    cfg.update(device=gpu)
+    torch.manual_seed(5)
+    layer = R.ProjectionLayer(cfg, 512).eval()
+    with torch.no_grad():
+        layer.attention_score.bias.normal_(0, 0.1)
+        layer.attention_final.bias.normal_(0, 0.1)
+    x = torch.randn(70, 5, 512, device=gpu)
+    a = layer.get_attention_weights(x)
+    xd = x.double()
+    s = torch.tanh(xd @ layer.attention_score.weight.double().T + layer.attention_score.bias.double()) @ \
+        layer.attention_final.weight.double().T + layer.attention_final.bias.double()
+    ref = torch.softmax(s, dim=1)
+    assert a.shape == (70, 5, 1) and float((a.double() - ref).abs().max()) < 1e-5
+    assert float((a.sum(1) - 1).abs().max()) < 1e-5
+    with torch.no_grad():
+        full = layer(x)
+        assert torch.equal(layer.memory_efficient_forward(x, chunk_size=32), full)
+        assert torch.equal(layer.memory_efficient_forward(x[:8], chunk_size=32), full[:8])
+    assert layer.profile_performance((4, 5, 512), num_iterations=3) > 0
