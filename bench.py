@@ -340,7 +340,9 @@ def main():
         from oracle import cpu_baseline as CB
         w0, o0 = batches[0][0], batches[0][3]
         db_h = rows.cpu().numpy()
-        cores = len(os.sched_getaffinity(0))
+        # threads actually used: the CPUs this process may run on, at most 16 (a one-GPU box is a 16-CPU share of its host;
+        # more threads than that share only fight each other: 256 threads took 10x longer than 16) -- RADAD_CPU_THREADS overrides
+        cores = int(os.environ.get("RADAD_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
         if args.cpu_baseline_clips > 0:
             nb = min(args.cpu_baseline_clips, B)
             wav_b = [w0[o0[b]:o0[b + 1]].cpu().numpy() for b in range(nb)]

@@ -944,28 +944,49 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
             }
         }
     }
-    // 2) float64 re-score of the candidates
-    const float* qrow = p.q + q * p.dim;
-    for (int c = 0; c < nsel; ++c) {
-        double acc = 0.0;
-        for (int i = lane * 4; i < p.dim; i += 256) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + i);
-            f32x4 b;
-            if (p.db_f16) {
-                const f16x4 h4 = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.db) + (int64_t)c_id[c] * p.dim + i);
-                b = f32x4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
-            } else {
-                b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.db) + (int64_t)c_id[c] * p.dim + i);
+    // 2) float64 re-score of the candidates.  A quarter-wave (16 lanes) per candidate, four candidates per pass and the
+    //    loads of a whole pass issued before the first multiply: the stored rows are random 2 KB reads, and with hundreds of
+    //    candidates per query (dense near-ties) the pass is latency-bound unless many rows are in flight.
+    {
+        const float* qrow = p.q + q * p.dim;
+        const int sub = lane >> 4, l16 = lane & 15;
+        for (int c0 = 0; c0 < nsel; c0 += 4) {
+            const int c = c0 + sub;
+            const bool on = c < nsel;
+            const int64_t rid = on ? (int64_t)c_id[c] : 0;
+            double acc = 0.0;
+            for (int i0 = 0; i0 < p.dim; i0 += 512) {                 // 16 lanes x 8 x 4 elements per sweep
+                f32x4 b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + (u * 16 + l16) * 4;
+                    b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (on && i < p.dim) {
+                        if (p.db_f16) {
+                            const f16x4 h4 = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.db) + rid * p.dim + i);
+                            b[u] = f32x4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+                        } else {
+                            b[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.db) + rid * p.dim + i);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + (u * 16 + l16) * 4;
+                    if (i < p.dim) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + i);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (p.l2) { const double d = (double)a[e] - (double)b[u][e]; acc += d * d; }
+                            else acc += (double)a[e] * (double)b[u][e];
+                        }
+                    }
+                }
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (p.l2) { const double d = (double)a[e] - (double)b[e]; acc += d * d; }
-                else acc += (double)a[e] * (double)b[e];
-            }
+            for (int ofs = 8; ofs > 0; ofs >>= 1) acc += __shfl_xor(acc, ofs, 64);
+            if (on && l16 == 0) c_key[c] = acc;
         }
-#pragma unroll
-        for (int ofs = 32; ofs > 0; ofs >>= 1) acc += __shfl_xor(acc, ofs, 64);
-        if (lane == 0) c_key[c] = acc;
     }
     // 3) rank by (distance, id): L2 ascending, IP descending; ids are unique so ranks are a permutation
     for (int c = lane; c < nsel; c += 64) {
@@ -1801,9 +1822,17 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         wp.n = h->ntotal; wp.nq = (int)nq; wp.row_bytes = h->dim * 2; wp.l2 = l2;
         wp.n_qtiles = n_qtiles; wp.n_splits = n_splits; wp.chunk_rows = chunk_rows; wp.part_score = ps; wp.part_idx = pi;
         wp.thr_init = nullptr; wp.qflag = qflag;
-        wp.debug = 0;
+        wp.debug = 0; wp.stamps = nullptr;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (make exp); never in the shipped library
         { const char* dbg = getenv("RADAD_DEBUG_KNN"); wp.debug = dbg ? atoi(dbg) : 0; }
+        {   // RADAD_KNN_STAMPS=<file>: in-kernel s_memtime stamps of waves 0 and 4 of workgroup 0, dumped after the scan (synchronises)
+            static unsigned long long* stamp_buf = nullptr;
+            if (getenv("RADAD_KNN_STAMPS")) {
+                if (!stamp_buf) (void)hipMalloc(&stamp_buf, 2 * 4096 * 8);
+                (void)hipMemsetAsync(stamp_buf, 0, 2 * 4096 * 8, st);
+                wp.stamps = stamp_buf;
+            }
+        }
 #endif
         const int rsc = l2 ? 2 : (wp.rscale ? 1 : 0);
         const size_t lds = knn_hi_lds_bytes();
@@ -1833,6 +1862,14 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         else if (rsc == 1) hipLaunchKernelGGL(k_knn_hi<1>, grid, b, lds, st, wp);
         else hipLaunchKernelGGL(k_knn_hi<2>, grid, b, lds, st, wp);
         h->prof.end(st);
+#ifdef RADAD_DEBUG_HOOKS
+        if (wp.stamps) {
+            std::vector<unsigned long long> hs(2 * 4096);
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(hs.data(), wp.stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+            if (FILE* f = fopen(getenv("RADAD_KNN_STAMPS"), "wb")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
+        }
+#endif
     } else if (smallq) {
         SmallQParams sp;
         sp.db = (const float*)h->rows; sp.ynorm = h->ynorm; sp.q = q_use; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel;
