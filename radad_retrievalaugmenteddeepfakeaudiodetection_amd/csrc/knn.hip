@@ -832,46 +832,54 @@ struct RefineParams {
     float* out_dist;          // [nq, k]
     int64_t* out_idx;         // [nq, k]
     double* out_key;          // optional [nq, k] float64 distances
-    int waves_per_block;
 };
 
-__global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_m[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int64_t q = (int64_t)blockIdx.x * p.waves_per_block + wave;
-    if (wave >= p.waves_per_block || q >= p.nq) return;
-    // per-wave LDS: double key[cap] | int id[cap] | int pos[n_parts] | int end[n_parts]
-    const size_t per_wave = (size_t)p.cap * 12 + (size_t)p.n_parts * 8;
-    char* base = smem_m + (((size_t)wave * per_wave + 15) & ~(size_t)15) + (size_t)wave * 16;
-    double* c_key = reinterpret_cast<double*>(base);
-    int* c_id = reinterpret_cast<int*>(base + (size_t)p.cap * 8);
-    int* s_pos = c_id + p.cap;
-    int* s_end = s_pos + p.n_parts;
-    for (int i = lane; i < p.n_parts; i += 64) s_pos[i] = 0;
+// One workgroup (256 threads) per query: thread t looks after lists t, t + 256, ... (<= RF_MAXL of them); the k rounds
+// are block-wide arg-max reductions over cached list heads (only the winning list re-reads its head), the walk to tau and
+// the append are parallel over the lists, the float64 re-score runs 16 candidates per pass (16 lanes each, all loads of a
+// pass in flight), the ranking is one thread per candidate.
+constexpr int RF_THREADS = 256;
+constexpr int RF_MAXL = 4;               // lists per thread: n_parts <= 1024
 
-    // 1) candidates (a wave only touches its own LDS slice: program order suffices).
-    //    First the k best by scan score, by k rounds of "wave-wide best list head, the winning list advances" (legacy mode:
-    //    `cap` rounds, and that is all); that fixes a_k and tau = a_k - 2 eps.  Then every lane walks on through its own
-    //    lists and appends the entries >= tau (sorted lists: stop at the first one below) -- no more rounds, whatever the
-    //    number of near-ties.
+__global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_m[];
+    double* c_key = reinterpret_cast<double*>(smem_m);                   // [cap]
+    int* c_id = reinterpret_cast<int*>(c_key + p.cap);                   // [cap]
+    float* w_sc = reinterpret_cast<float*>(c_id + p.cap);                // [2][4] per-wave winners of a round (double-buffered)
+    int* w_id = reinterpret_cast<int*>(w_sc + 8);                        // [2][4]
+    int* w_pt = w_id + 8;                                                // [2][4]
+    int* w_cnt = w_pt + 8;                                               // [4] per-wave counts of the append
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q = blockIdx.x;
     const bool cert = p.eps != nullptr;
     const float two_eps = cert ? 2.f * p.eps[q] : 0.f;
-    float tau = -INFINITY;                   // defined once k candidates are in
+    const int64_t qbase = q * p.n_parts;
+
+    // cached heads of this thread's lists
+    int pos[RF_MAXL];
+    float hsc[RF_MAXL];
+    int hid[RF_MAXL];
+    auto fetch = [&](int part, int at, float& sc, int& id) {
+        id = IDX_SENTINEL; sc = -INFINITY;
+        if (part < p.n_parts && at < p.part_len) {
+            const int64_t off = (qbase + part) * p.part_len + at;
+            id = p.idx[off];
+            if (id != IDX_SENTINEL) sc = p.score[off];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < RF_MAXL; ++i) { pos[i] = 0; fetch(tid + RF_THREADS * i, 0, hsc[i], hid[i]); }
+
+    // 1) the k best by scan score (legacy mode: `cap` of them, and that is all): fixes a_k and tau = a_k - 2 eps
+    float tau = -INFINITY;
     int nsel = 0;
     const int rounds = cert ? min(p.k, p.cap) : p.cap;
     for (int o = 0; o < rounds; ++o) {
         float bs = -INFINITY;
         int bi = IDX_SENTINEL, bp = -1;
-        for (int part = lane; part < p.n_parts; part += 64) {
-            const int pos = s_pos[part];
-            if (pos >= p.part_len) continue;
-            const int64_t off = ((int64_t)q * p.n_parts + part) * p.part_len + pos;
-            const int id = p.idx[off];
-            if (id == IDX_SENTINEL) continue;
-            const float sc = p.score[off];
-            if (bp < 0 || sc > bs || (sc == bs && id < bi)) { bs = sc; bi = id; bp = part; }
-        }
+#pragma unroll
+        for (int i = 0; i < RF_MAXL; ++i)
+            if (hid[i] != IDX_SENTINEL && (bp < 0 || hsc[i] > bs || (hsc[i] == bs && hid[i] < bi))) { bs = hsc[i]; bi = hid[i]; bp = tid + RF_THREADS * i; }
 #pragma unroll
         for (int ofs = 32; ofs > 0; ofs >>= 1) {
             const float os = __shfl_xor(bs, ofs, 64);
@@ -879,64 +887,80 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
             const int op = __shfl_xor(bp, ofs, 64);
             if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
         }
-        if (bp < 0) break;                                   // every list exhausted (wave-uniform)
-        if ((bp & 63) == lane) s_pos[bp] += 1;
-        if (lane == 0) c_id[nsel] = bi;
+        const int slot = (o & 1) * 4;
+        if (lane == 0) { w_sc[slot + wave] = bs; w_id[slot + wave] = bi; w_pt[slot + wave] = bp; }
+        __syncthreads();
+        bs = w_sc[slot]; bi = w_id[slot]; bp = w_pt[slot];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float os = w_sc[slot + w];
+            const int oi = w_id[slot + w], op = w_pt[slot + w];
+            if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
+        }
+        if (bp < 0) break;                                   // every list exhausted (block-uniform)
+        if ((bp & (RF_THREADS - 1)) == tid) {
+#pragma unroll
+            for (int i = 0; i < RF_MAXL; ++i)
+                if (bp == tid + RF_THREADS * i) { pos[i] += 1; fetch(bp, pos[i], hsc[i], hid[i]); }
+        }
+        if (tid == 0) c_id[nsel] = bi;
         ++nsel;
         if (cert && nsel == p.k) tau = bs - two_eps;
     }
     if (cert) {
         int why = 0;                         // bit 0: candidate buffer full, 1: a full list used up, 2: admission floor above tau, 3: dropped
-        for (int part = lane; part < p.n_parts; part += 64) s_end[part] = s_pos[part];
-        if (nsel == p.k) {
-            // every lane walks on through its own lists: entries [s_pos, s_end) are >= tau (sorted lists: stop at the first below)
-            for (int part = lane; part < p.n_parts; part += 64) {
-                int pos = s_pos[part];
-                const int64_t lb = ((int64_t)q * p.n_parts + part) * p.part_len;
-                while (pos < p.part_len) {
-                    const int id = p.idx[lb + pos];
-                    if (id == IDX_SENTINEL || p.score[lb + pos] < tau) break;
-                    ++pos;
-                }
-                s_end[part] = pos;
-            }
-            // append them: 64 lists per sweep, slots by a prefix sum over the lanes
-            for (int p0 = 0; p0 < p.n_parts; p0 += 64) {
-                const int part = p0 + lane;
-                const int first = part < p.n_parts ? s_pos[part] : 0;
-                const int cnt = part < p.n_parts ? s_end[part] - first : 0;
-                int incl = cnt;
+        int cnt = 0, used_up = 0;
+        int endp[RF_MAXL];
 #pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int t = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += t;
+        for (int i = 0; i < RF_MAXL; ++i) {
+            const int part = tid + RF_THREADS * i;
+            int e = pos[i];
+            if (nsel == p.k && part < p.n_parts) {           // walk on while the entries are >= tau (sorted lists)
+                const int64_t lb = (qbase + part) * p.part_len;
+                while (e < p.part_len) {
+                    const int id = p.idx[lb + e];
+                    if (id == IDX_SENTINEL || p.score[lb + e] < tau) break;
+                    ++e;
                 }
-                const int total = __shfl(incl, 63, 64);
-                const int base_slot = nsel + incl - cnt;
-                if (cnt > 0) {
-                    const int64_t lb = ((int64_t)q * p.n_parts + part) * p.part_len;
-                    for (int j = 0; j < cnt; ++j)
-                        if (base_slot + j < p.cap) c_id[base_slot + j] = p.idx[lb + first + j];
-                }
-                nsel += total;
             }
-            if (nsel > p.cap) { nsel = p.cap; why |= 1; }
+            endp[i] = e;
+            cnt += e - pos[i];
+            // a full list whose entries are ALL >= tau may hide more such rows; everything else a list hides is below its
+            // first entry < tau (or, for a list that never filled up, below the admission floor)
+            if (part < p.n_parts && e >= p.part_len && p.idx[(qbase + part) * p.part_len + p.part_len - 1] != IDX_SENTINEL) used_up = 1;
         }
-        // a full list whose entries are ALL >= tau may hide more such rows; everything else a list hides is below its
-        // first entry < tau (or, for a list that never filled up, below the admission floor)
-        int bad = 0;
-        for (int part = lane; part < p.n_parts; part += 64)
-            if (s_end[part] >= p.part_len &&
-                p.idx[((int64_t)q * p.n_parts + part) * p.part_len + p.part_len - 1] != IDX_SENTINEL) bad = 1;
+        // slots by a prefix sum over the block (lists in thread order)
+        int incl = cnt;
 #pragma unroll
-        for (int ofs = 32; ofs > 0; ofs >>= 1) bad |= __shfl_xor(bad, ofs, 64);
-        if (bad) why |= 2;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) w_cnt[wave] = incl;
+        used_up = __syncthreads_or(used_up);
+        int base_slot = nsel + incl - cnt, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (w < wave) base_slot += w_cnt[w]; total += w_cnt[w]; }
+#pragma unroll
+        for (int i = 0; i < RF_MAXL; ++i) {
+            const int part = tid + RF_THREADS * i;
+            const int n_i = endp[i] - pos[i];
+            if (n_i > 0) {
+                const int64_t lb = (qbase + part) * p.part_len;
+                for (int j = 0; j < n_i; ++j)
+                    if (base_slot + j < p.cap) c_id[base_slot + j] = p.idx[lb + pos[i] + j];
+                base_slot += n_i;
+            }
+        }
+        nsel += total;
+        if (nsel > p.cap) { nsel = p.cap; why |= 1; }
+        if (used_up) why |= 2;
         if (p.thr_init) {
             const float fl = p.thr_init[q];
             if (fl > -INFINITY && !(nsel >= p.k && fl <= tau)) why |= 4;      // rows below the floor are unlisted
         }
         if (p.qflag && p.qflag[q]) why |= 8;
-        if (lane == 0) {
+        if (tid == 0) {
             if (why) p.flag_sel[atomicAdd(p.flag_count, 1)] = (int)q;
             if (p.stats) {
                 atomicAdd(&p.stats[0], nsel);
@@ -944,13 +968,13 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
             }
         }
     }
-    // 2) float64 re-score of the candidates.  A quarter-wave (16 lanes) per candidate, four candidates per pass and the
-    //    loads of a whole pass issued before the first multiply: the stored rows are random 2 KB reads, and with hundreds of
-    //    candidates per query (dense near-ties) the pass is latency-bound unless many rows are in flight.
+    __syncthreads();                         // c_id complete
+    // 2) float64 re-score: 16 lanes per candidate, 16 candidates per pass, the loads of a pass issued before the first
+    //    multiply (the stored rows are random 2 KB reads: latency-bound unless many are in flight)
     {
         const float* qrow = p.q + q * p.dim;
-        const int sub = lane >> 4, l16 = lane & 15;
-        for (int c0 = 0; c0 < nsel; c0 += 4) {
+        const int sub = tid >> 4, l16 = tid & 15;
+        for (int c0 = 0; c0 < nsel; c0 += 16) {
             const int c = c0 + sub;
             const bool on = c < nsel;
             const int64_t rid = on ? (int64_t)c_id[c] : 0;
@@ -988,8 +1012,9 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
             if (on && l16 == 0) c_key[c] = acc;
         }
     }
-    // 3) rank by (distance, id): L2 ascending, IP descending; ids are unique so ranks are a permutation
-    for (int c = lane; c < nsel; c += 64) {
+    __syncthreads();
+    // 3) rank by (distance, id): L2 ascending, IP descending; ids are unique so ranks are a permutation.  One thread per candidate.
+    for (int c = tid; c < nsel; c += RF_THREADS) {
         const double kc = c_key[c];
         const int64_t ic = p.id_map ? p.id_map[c_id[c]] : (int64_t)c_id[c];
         int rank = 0;
@@ -1005,7 +1030,7 @@ __global__ __launch_bounds__(256) void k_merge_refine(RefineParams p) {
             if (p.out_key) p.out_key[q * p.k + rank] = kc;
         }
     }
-    for (int o = nsel + lane; o < p.k; o += 64) {   // faiss fills what it cannot find with -1 / +-inf
+    for (int o = nsel + tid; o < p.k; o += RF_THREADS) {   // faiss fills what it cannot find with -1 / +-inf
         p.out_dist[q * p.k + o] = p.l2 ? INFINITY : -INFINITY;
         p.out_idx[q * p.k + o] = -1;
         if (p.out_key) p.out_key[q * p.k + o] = p.l2 ? (double)INFINITY : -(double)INFINITY;
@@ -1037,6 +1062,7 @@ struct ExactParams {
     int* pidx;
     int64_t id_base;
     float* out_dist; int64_t* out_idx; double* out_key;
+    int* host_stats;           // pinned host memory (device-visible): k_exact_merge leaves the search's 6 counters there
 };
 
 __device__ __forceinline__ bool kx_better(double ka, int ia, double kb, int ib) { return ka > kb || (ka == kb && ia < ib); }
@@ -1146,6 +1172,7 @@ __global__ __launch_bounds__(KX_THREADS) void k_exact_scan(ExactParams p) {
 // one wave per rejected query: merge its KX_SLICES partial lists, overwrite the query's output rows
 __global__ __launch_bounds__(256) void k_exact_merge(ExactParams p) {
     const int count = *p.count;
+    if (blockIdx.x == 0 && threadIdx.x < 6 && p.host_stats) p.host_stats[threadIdx.x] = p.count[threadIdx.x];   // count + 5 statistics
     const int lane = threadIdx.x & 63;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= count) return;
@@ -1379,6 +1406,7 @@ struct radad_knn_s {
     // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
     // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
     int* host_count = nullptr;   // pinned [8]: rejected queries, sum of candidates, rejections by reason x 4
+    int* host_count_dev = nullptr;   // the same memory as the device sees it
     hipEvent_t ev_count = nullptr, ev_done = nullptr;
     bool count_pending = false, done_recorded = false;
     int64_t count_nq = 0;        // batch size of the search host_count belongs to
@@ -1474,6 +1502,7 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
         hp.hi = have_plane ? h->hi + (size_t)from * h->dim : nullptr;
         hp.scale_out = (have_plane && h->rscale) ? h->rscale + from : nullptr;
         hp.stat_max = h->stat; hp.eps_out = nullptr; hp.ystat = nullptr;
+        hp.norm_out = nullptr; hp.zero_flags = nullptr; hp.zero_counters = nullptr;
         hp.n = h->ntotal - from; hp.dim = h->dim;
         // cosine rows have |x| <= 1: one scale for the whole store (no per-score arithmetic in the scan);
         // an fp16 store is its own plane: statistics only, un-scaled
@@ -1530,6 +1559,11 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
             return RADAD_EHIP;
         }
         memset(h->host_count, 0, 8 * sizeof(int));
+        if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h->host_count_dev), h->host_count, 0) != hipSuccess) {
+            radad_set_error("radad_knn_create: pinned counter is not device-visible");
+            radad_knn_destroy(h);
+            return RADAD_EHIP;
+        }
     }
     *out = h;
     return RADAD_OK;
@@ -1786,13 +1820,14 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)ceil_div64(ne, 1024)), dim3(256), 0, st, (const unsigned short*)q_in, qf, ne);
         q_use = qf;
     }
+    const bool prep = cert || use_hi || f16_tile;          // k_hi_rows runs: it also normalises and clears the flags
     if (h->metric == RADAD_METRIC_COSINE) {
         float* qn = (float*)(ws + o_qn);
-        hipLaunchKernelGGL(k_rows_prepare<float>, dim3(rgrid), dim3(256), 0, st, q_use, qn, (float*)nullptr, nq, h->dim, 2);
-        q_use = qn;
+        if (!prep) hipLaunchKernelGGL(k_rows_prepare<float>, dim3(rgrid), dim3(256), 0, st, q_use, qn, (float*)nullptr, nq, h->dim, 2);
+        // (with prep the same normalisation happens inside k_hi_rows, which reads the raw queries)
     }
     // (|q|^2 is not needed: ranking uses 2 q.y - |y|^2 and the reported distance is re-scored exactly)
-    if (cert || use_hi || f16_tile) {
+    if (prep) {
         HiRowsParams hp;
         hp.in = q_use; hp.in_f16 = 0;
         hp.hi = (use_hi || f16_tile) ? qh : nullptr;
@@ -1801,9 +1836,11 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         hp.n = nq; hp.dim = h->dim;
         hp.fixed_e = use_hi ? HI_E_PER_ROW : 0;          // the fp16 tile kernel multiplies un-scaled fp16 queries
         hp.l2 = l2; hp.exact_ops = (use_hi || f16_tile) ? 0 : 1;
+        hp.norm_out = h->metric == RADAD_METRIC_COSINE ? (float*)(ws + o_qn) : nullptr;
+        hp.zero_flags = cert ? qflag : nullptr; hp.zero_counters = cert ? flag_count : nullptr;
         hipLaunchKernelGGL(k_hi_rows, dim3(rgrid), dim3(256), 0, st, hp);
     }
-    if (cert) RADAD_HIP_CHECK(hipMemsetAsync(qflag, 0, b_vec + 256, st));      // qflag and flag_count
+    if (h->metric == RADAD_METRIC_COSINE) q_use = (const float*)(ws + o_qn);
     RADAD_HIP_CHECK(hipGetLastError());
 
     // ---- scan ----------------------------------------------------------------------------------------------------
@@ -1924,10 +1961,9 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     m.db = h->rows; m.db_f16 = h->f16; m.q = q_use; m.id_map = nullptr; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
     m.out_key = out_key_dev;
     m.stats = cert ? flag_count + 1 : nullptr;
-    const size_t per_wave = (((size_t)cap * 12 + (size_t)n_splits * 8 + 15) & ~(size_t)15) + 16;
-    m.waves_per_block = (int)std::max<size_t>(1, std::min<size_t>(4, (60 * 1024) / per_wave));
-    hipLaunchKernelGGL(k_merge_refine, dim3((unsigned)ceil_div64(nq, m.waves_per_block)), dim3(256),
-                       per_wave * m.waves_per_block + 64, st, m);
+    RADAD_REQUIRE(n_splits <= RF_THREADS * RF_MAXL, "radad_knn_search: %d partial lists per query exceed the re-rank kernel's %d", n_splits,
+                  RF_THREADS * RF_MAXL);
+    hipLaunchKernelGGL(k_merge_refine, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)cap * 12 + 256, st, m);
     RADAD_HIP_CHECK(hipGetLastError());
 
     // ---- the queries the certificate rejected: exact float64 search, sized and driven by the device-side count ------
@@ -1938,14 +1974,14 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         x.slice_rows = ceil_div64(std::max<int64_t>(h->ntotal, 1), KX_SLICES);
         x.pkey = (double*)(ws + o_xk); x.pidx = (int*)(ws + o_xi); x.id_base = h->id_base;
         x.out_dist = out_dist_dev; x.out_idx = out_idx_dev; x.out_key = out_key_dev;
+        x.host_stats = h->host_count_dev;
         const size_t xlds = (size_t)xgroup * h->dim * 4 + (size_t)KX_WAVES * xgroup * k * 12 + 16;
         RADAD_REQUIRE(xlds <= 160 * 1024, "radad_knn_search: dim %d x k %d too large for the exact kernel", h->dim, k);
         RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_exact_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
         hipLaunchKernelGGL(k_exact_scan, dim3(KX_SLICES, KX_GROUPS_Y), dim3(KX_THREADS), xlds, st, x);
         hipLaunchKernelGGL(k_exact_merge, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, x);
         RADAD_HIP_CHECK(hipGetLastError());
-        RADAD_HIP_CHECK(hipMemcpyAsync(h->host_count, flag_count, 6 * sizeof(int), hipMemcpyDeviceToHost, st));
-        RADAD_HIP_CHECK(hipEventRecord(h->ev_count, st));
+        RADAD_HIP_CHECK(hipEventRecord(h->ev_count, st));      // (k_exact_merge has written the counters to the pinned host copy)
         h->count_pending = true;
         h->count_nq = nq;
     }
