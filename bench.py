@@ -41,10 +41,10 @@ PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32
 PEAK_MFMA_F16_TFLOPS = 2500.0     # same guide: BF16/F16 MFMA ~2.5 PF dense (at 2.4 GHz; MFMA-dense loops hold 1.5-1.95 GHz)
 PEAK_HBM_GBPS = 8000.0
 # HBM-side bytes of ONE scan launch of the default 1-GPU workload, from the PMC passes of the same command
-# (profiles/r2_*_pmc_summary.txt, tools/profile_r1.sh): FETCH_SIZE x 2 (gfx950 reports half of a 16-B/lane stream,
-# MI355X_MICROARCH.md "HBM") + WRITE_SIZE.  Infinity-Cache hits are counted in FETCH_SIZE, so this is an upper bound on
-# DRAM traffic; it is only meaningful for that exact workload (None until measured for the kernel that runs).
-SCAN_TRAFFIC_BYTES = {"k_knn_hi": None, "k_knn_f32_reg": 4.18399e6 * 1024 * 2 + 8195.59 * 1024}
+# (profiles/r2_d_pmc_summary.txt, tools/profile_r1.sh): FETCH_SIZE (KB) x 2 (gfx950 reports half of a 16-B/lane stream,
+# MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KB).  Infinity-Cache hits are counted in FETCH_SIZE, so this is an upper bound on
+# DRAM traffic; it is only meaningful for that exact workload.  k_knn_hi reads the f16 hi plane (1.024 GB) once: 1.04x.
+SCAN_TRAFFIC_BYTES = {"k_knn_hi": 509305.0 * 1024 * 2 + 18944.1 * 1024, "k_knn_f32_reg": 4.18399e6 * 1024 * 2 + 8195.59 * 1024}
 
 
 def main():
@@ -372,6 +372,7 @@ def main():
                      "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic,
                      "kernel_ms": round(knn_avg, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_operand_bytes_per_launch": (2.0 * (hi - lo) * DIM + 2.0 * Q * DIM + 8.0 * Q * launch["db_splits"] * 16) if wide else alg_bytes,
                      "hbm_GBps_algorithmic": round(alg_bytes / (knn_avg * 1e-3) / 1e9, 1),
                      "queries_rejected_by_certificate_last_step": rechecked,
                      "launch": launch},

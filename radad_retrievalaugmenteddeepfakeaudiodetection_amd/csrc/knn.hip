@@ -1520,7 +1520,10 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
 static void knn_geometry_wide(int64_t n, int64_t nq, int* n_qtiles, int* n_splits, int64_t* chunk_rows) {
     const int qt = (int)ceil_div64(nq, KW_N);
     const int64_t tiles = ceil_div64(n, KW_M);
-    int64_t want = ceil_div64(512, qt);
+    // >= 512 workgroups, and >= 64 chunks however many query tiles there are: every (query, chunk) keeps 16 candidates, and on
+    // stores of near-duplicates (the benchmark: ~150 rows within the certificate's threshold per query) 16 chunks would see
+    // one list in thirty used up and send a third of the batch to the exact kernel (the 8-GPU per-rank shape: 32 query tiles)
+    int64_t want = std::max<int64_t>(ceil_div64(512, qt), 64);
     want = std::min<int64_t>(want, tiles);
     want = std::max<int64_t>(8, ceil_div64(want, 8) * 8);
     want = std::min<int64_t>(want, 1024);
@@ -1890,7 +1893,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
             else if (rsc == 1) hipLaunchKernelGGL(k_knn_hi_sample<1>, sg, sb, lds, st, sp);
             else hipLaunchKernelGGL(k_knn_hi_sample<2>, sg, sb, lds, st, sp);
             hipLaunchKernelGGL(k_thr_from_parts, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, ps, pi, sp.n_splits * 8, 2,
-                               k + margin, nq, thr_init);
+                               k + margin, nq, thr_init, (const float*)eps);
             wp.thr_init = thr_init;
         }
         const dim3 b(KW_THREADS);

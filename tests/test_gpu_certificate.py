@@ -63,19 +63,19 @@ def test_near_ties_around_rank_k_pass_by_certificate(gpu, metric):
 @pytest.mark.parametrize("metric", ["COSINE", "L2"])
 @pytest.mark.parametrize("f16", [False, True])
 def test_duplicates_and_dense_ties_take_the_exact_kernel(gpu, metric, f16):
-    """(a) 100 exact copies of one row inside ONE chunk (its 16-entry list is used up), (b) 300 near-ties spread over the
-    store (more than the candidate buffer holds): neither query can be certified; the exact float64 kernel must return
-    the brute-force result, ties to the lower id.  Every other query must still be certified."""
+    """(a) 100 exact copies of one row inside ONE chunk (its 16-entry list is used up), (b) 700 near-ties spread over the
+    store (more than the 512-entry candidate buffer holds): neither query can be certified; the exact float64 kernel must
+    return the brute-force result, ties to the lower id.  Every other query must still be certified."""
     n, nq, dim, k = 50000, 80, 64, 15
     db = synth.rows(0, n, dim, 7101)
     q = synth.rows(0, nq, dim, 7102)
-    dup = q[7] + np.float32(0.05) * synth.rows(0, 1, dim, 7103)[0]
-    db[20000:20100] = dup                                # (a)
     near = q[33] + np.float32(0.05) * synth.rows(1, 1, dim, 7103)[0]
-    for t in range(300):                                 # (b)
+    for t in range(700):                                 # (b)
         row = near.copy()
         row[t % dim] += np.float32(3e-4 * ((t * 7) % 11 - 5))
-        db[(t * 163 + 11) % n] = row
+        db[(t * 67 + 11) % n] = row
+    dup = q[7] + np.float32(0.05) * synth.rows(0, 1, dim, 7103)[0]
+    db[20000:20100] = dup                                # (a)
     idx = _index(metric, dim, f16=f16)
     idx.add(db)
     D, I = idx.search(q, k)
@@ -93,7 +93,8 @@ def test_duplicates_and_dense_ties_take_the_exact_kernel(gpu, metric, f16):
     np.testing.assert_array_equal(I, oi)
     np.testing.assert_allclose(D, od, rtol=1e-6, atol=1e-6)
     assert list(I[7]) == list(range(20000, 20000 + k))   # exact ties: lower ids first
-    assert 2 <= info["rechecked_queries"] <= 6, info
+    cert = info["certificate"]
+    assert 2 <= cert["rejected"] <= 6 and cert["rejected_list_used_up"] >= 1 and cert["rejected_buffer_full"] >= 1, info
 
 
 def test_bf16_queries_on_fp16_store(gpu):

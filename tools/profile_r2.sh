@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round-2 profile set (run through gpurun): kernel stats, PMC passes, and the bench records copied to profiles/ afterwards.
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+T=$1
+bash tools/profile_stats.sh ${T} > /dev/null 2>&1
+bash tools/profile_r1.sh ${T} > gpurun_out/pmc_${T}.out 2>&1
+python bench.py > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
+python bench.py --workload ragged --pcie 0 > gpurun_out/${T}_bench_ragged.json 2> /dev/null
+python bench.py --store-dtype f16 --cpu-baseline-clips 0 --pcie 0 --sustain 0 > gpurun_out/${T}_bench_f16.json 2> /dev/null
+python bench.py --store-dtype f16 --embed-dtype bf16 --cpu-baseline-clips 0 --pcie 0 --sustain 0 > gpurun_out/${T}_bench_bf16_f16.json 2> /dev/null
+python bench.py --scan f32 --cpu-sample 0 --cpu-baseline-clips 0 --pcie 0 --sustain 0 > gpurun_out/${T}_bench_scan_f32.json 2> /dev/null
+python bench.py --mode predict --steps 200 --warmup 10 > gpurun_out/${T}_predict_1.json 2> /dev/null
+python bench.py --mode predict --predict-queries 16 --steps 200 --warmup 10 > gpurun_out/${T}_predict_16.json 2> /dev/null
+for f in default ragged f16 bf16_f16 scan_f32; do python - <<PY
+import json
+d=json.load(open("gpurun_out/${T}_bench_$f.json"))
+print("$f", d["value"], d["ms_per_step"], d["kernels_ms"], d.get("sustained",{}).get("value"), d.get("pcie_inclusive",{}).get("value"), d.get("cpu_baseline",{}).get("value"), d.get("parity_on_sample",{}).get("ids_bit_exact"), d["roofline"]["launch"].get("certificate"))
+PY
+done
+for f in predict_1 predict_16; do python -c "
+import json; d=json.load(open('gpurun_out/${T}_$f.json')); print('$f', d['value'], d['roofline']['achieved'], d['roofline']['kernel_ms'])"; done

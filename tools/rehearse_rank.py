@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""What ONE rank of an N-GPU `bench.py --gpus N` run computes, reproduced in a single process on one GPU (the other ranks'
+query blocks are embedded locally instead of all-gathered): the shard of the 1 M x 512 store with its share of the planted
+rows, all N x 1024 queries.  Prints the scan time, the search time and the certificate's statistics for that per-rank shape.
+usage: python tools/rehearse_rank.py --world 8 [--rank 0]"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import shard_bounds
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--rank", type=int, default=0)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+lib = _lib.load()
+B, S, N, D, K = 1024, 64000, 1_000_000, 512, 10
+cfg = R.Config()
+cfg.update(device=dev, tpp_levels=[1], tpp_pooling_type="max", feature_dim=D, vector_db_index_type="IP")
+fe = R.MelProjectionFeatureExtractor(cfg)
+embs = []
+wave = torch.empty(B * S, device=dev)
+offs = np.arange(B + 1, dtype=np.int64) * S
+for r in range(a.world):
+    _lib.check(lib.radad_synth_audio(wave.data_ptr(), r * B, B, S, 1234, 0, _lib.stream_ptr(dev)))
+    embs.append(fe.embed_clips(wave, offs).clone())
+all_emb = torch.cat(embs)
+Q = a.world * B
+lo, hi = shard_bounds(N, a.world, a.rank)
+rows = torch.empty((hi - lo, D), device=dev)
+_lib.check(lib.radad_synth_rows(rows.data_ptr(), lo, hi - lo, D, 4321, 0, _lib.stream_ptr(dev)))
+noise = torch.empty((2 * Q, D), device=dev)
+_lib.check(lib.radad_synth_rows(noise.data_ptr(), 0, 2 * Q, D, 99, 0, _lib.stream_ptr(dev)))
+jj = torch.arange(Q, device=dev)
+scale = all_emb.norm(dim=1, keepdim=True) / (D ** 0.5)
+for c, eps in ((0, 0.05), (1, 0.10)):
+    g = (jj * 977 + c * 350003 + 17) % N
+    mine = (g >= lo) & (g < hi)
+    rows[g[mine] - lo] = all_emb[mine] + eps * scale[mine] * noise[c * Q:(c + 1) * Q][mine]
+idx = R.HipFlatIndex(D, _lib.METRIC_COSINE, 0, id_base=lo)
+idx.add_device(rows)
+idx.profile(True)
+for _ in range(2):
+    idx.search_device(all_emb, K, return_f64=True)
+idx.profile_read()
+t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+t0.record()
+for _ in range(a.reps):
+    idx.search_device(all_emb, K, return_f64=True)
+t1.record(); torch.cuda.synchronize()
+ms = idx.profile_read()
+print(json.dumps({"world": a.world, "rank": a.rank, "rows": hi - lo, "queries": Q, "scan_ms": round(float(np.mean(ms)), 4),
+                  "search_ms": round(t0.elapsed_time(t1) / a.reps, 4), "launch": idx.last_launch()}))
