@@ -75,14 +75,16 @@ struct LogmelParams {
     int padded;                  // P: virtual length after zero padding (== L in self mode)
     int nf;                      // frames actually computed per segment (<= 224)
     const float* basis;          // [NBT][NKK][2][64][4]                      (k_logmel: folded fp32 basis)
-    const _Float16* basis_h;     // [NBT*25][cos_hi, cos_lo, sin_hi, sin_lo][64][8]  (k_logmel_h: split-f16 basis x 2^11)
+    const _Float16* basis_h;     // [NBT][30 groups][4][64][8]: 25 x (cos_hi, cos_lo, sin_hi, sin_lo) x 2^11, then NMT x filter bank x 2^16 (k_logmel_h)
     const float* fbfrag;         // [NBT][NMT][16][64]
-    const _Float16* fbfrag_h;    // [NBT][NMT][2 k-halves][hi, lo][64][8]: filter bank x 2^16 in the k order of k_logmel_h
     unsigned nzmask;             // bit (bt*NMT+mt): that (bin tile, mel tile) block of the filter bank is non-zero
     float* logmel;               // [S][nf][80] log10(max(mel,1e-10))  (before the max-8 clamp)
     float* seg_max;              // [S] max over the segment (pre-initialised)
     float* norm_out;             // optional [S][L]: the normalised segment (stage parity); nullptr otherwise
     const int* n_seg_dev;        // optional: segments of the device-built plan (the grid is an upper bound; blocks beyond leave)
+    int split_f0;                // k_logmel_h: frames of a segment's first workgroup (the second takes the rest; >= nf: one workgroup)
+    int plane_halfs;             // k_logmel_h: halfs per LDS plane of a workgroup
+    int n_seg;                   // k_logmel_h: segments of this launch (its grid is rounded up)
     int debug;                   // timing experiments only (RADAD_DEBUG_LOGMEL): 1 = skip the MFMA loop, 2 = skip the prologue
 };
 
@@ -617,7 +619,6 @@ struct radad_embed_s {
     float *basis = nullptr, *fbfrag = nullptr, *wscale = nullptr, *bias = nullptr;
     _Float16* wfrag_h = nullptr;
     _Float16* basis_h = nullptr;
-    _Float16* fbfrag_h = nullptr;
     int logmel_f32 = 0;                  // RADAD_LOGMEL_F32=1: the fp32-MFMA kernel (k_logmel) instead of k_logmel_h
     int* levels_dev = nullptr;
     // plan cache + scratch
@@ -736,15 +737,19 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     LogmelParams p;
     p.wave = wave_dev; p.seg_start = (const int64_t*)h->seg_start.p; p.seg_valid = (const int*)h->seg_valid.p;
     p.seg_len = h->cfg.segment_length; p.normalize = h->cfg.normalize; p.padded = h->padded; p.nf = h->nf;
-    p.basis = h->basis; p.basis_h = h->basis_h; p.fbfrag = h->fbfrag; p.fbfrag_h = h->fbfrag_h; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
+    p.basis = h->basis; p.basis_h = h->basis_h; p.fbfrag = h->fbfrag; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
     p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out; p.n_seg_dev = n_seg_dev;
     p.debug = 0;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (tools/exp_logmel.sh builds with -DRADAD_DEBUG_HOOKS); never in the shipped library
     { const char* dbg = getenv("RADAD_DEBUG_LOGMEL"); p.debug = dbg ? atoi(dbg) : 0; }
 #endif
     h->prof_logmel.begin(st);
+    p.split_f0 = lh_split_f0(h->nf);
+    p.n_seg = (int)n_seg;
+    const int wg_frames = std::max(p.split_f0, h->nf - p.split_f0);
+    p.plane_halfs = lh_plane_halfs(wg_frames);
     if (h->logmel_f32) hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
-    else hipLaunchKernelGGL(k_logmel_h, dim3((unsigned)n_seg), dim3(LH_THREADS), logmel_h_lds_bytes(), st, p);
+    else hipLaunchKernelGGL(k_logmel_h, dim3((unsigned)(16 * ((n_seg + 7) / 8))), dim3(LH_THREADS), logmel_h_lds_bytes(wg_frames), st, p);
     h->prof_logmel.end(st);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
@@ -786,8 +791,8 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
     const int nf = std::min(T, nf_sig);
     RADAD_REQUIRE(nf <= LM_WAVES * 32, "radad_embed_create: %d frames per segment exceed the %d the kernel covers", nf, LM_WAVES * 32);
     RADAD_REQUIRE(padded == L || padded >= L + 2 * N_FFT, "radad_embed_create: padded_samples must be 0 or >= segment_length + 800");
-    RADAD_REQUIRE(FFT_HOP * (nf - 1) + N_FFT - 1 + 8 * ((FFT_HOP * (nf - 1) + N_FFT - 1) / FFT_HOP) + 8 <= LH_SIG_HALFS,
-                  "radad_embed_create: %d frames per segment exceed the LDS planes of k_logmel_h", nf);
+    RADAD_REQUIRE(std::max(lh_split_f0(nf), nf - lh_split_f0(nf)) <= LH_WG_FRAMES,
+                  "radad_create: %d frames per segment exceed the two workgroups of k_logmel_h", nf);
     int ndev = 0;
     RADAD_HIP_CHECK(hipGetDeviceCount(&ndev));
     RADAD_REQUIRE(device >= 0 && device < ndev, "radad_embed_create: device %d not in [0,%d)", device, ndev);
@@ -834,7 +839,7 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
                     }
                     const float cf = (float)(c * LH_BASIS_SCALE), sf = (float)(sn * LH_BASIS_SCALE);
                     const _Float16 chi = (_Float16)cf, shi_ = (_Float16)sf;
-                    const size_t base = (((size_t)(bt * LH_STEPS + step) * 4) * 64 + lane) * 8 + j;
+                    const size_t base = (((size_t)(bt * LH_GPB + step) * 4) * 64 + lane) * 8 + j;
                     basis_h[base] = chi;
                     basis_h[base + 1 * 512] = (_Float16)(cf - (float)chi);
                     basis_h[base + 2 * 512] = shi_;
@@ -855,8 +860,8 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
                     fbfrag[(((size_t)bt * NMT + mt) * 16 + r) * 64 + lane] = v;
                 }
     h->nzmask = nz;
-    // the same filter bank for k_logmel_h: f16 hi/lo of fb x 2^16, k' = 8 lh + j  <->  bin (j&3) + 16 h + 8 (j>>2) + 4 lh
-    std::vector<_Float16> fbfrag_h((size_t)NBT * NMT * 4 * 64 * 8);
+    // the same filter bank for k_logmel_h: f16 hi/lo of fb x 2^16, k' = 8 lh + j  <->  bin (j&3) + 16 h + 8 (j>>2) + 4 lh.  It rides in
+    // the basis stream: groups LH_STEPS .. LH_STEPS + NMT - 1 of each bin tile (the rest of the round stays zero padding)
     for (int bt = 0; bt < NBT; ++bt)
         for (int mt = 0; mt < NMT; ++mt)
             for (int hh = 0; hh < 2; ++hh)
@@ -868,9 +873,9 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
                         if (bin < N_BINS && mel < N_MELS) v = mel_filters_host[bin * N_MELS + mel];
                         const float sc = ldexpf(v, LH_FB_SHIFT);
                         const _Float16 vh = (_Float16)sc;
-                        const size_t base = ((((size_t)bt * NMT + mt) * 4 + hh * 2) * 64 + lane) * 8 + j;
-                        fbfrag_h[base] = vh;
-                        fbfrag_h[base + 512] = (_Float16)(sc - (float)vh);
+                        const size_t base = ((((size_t)bt * LH_GPB + LH_STEPS + mt) * 4 + hh * 2) * 64 + lane) * 8 + j;
+                        basis_h[base] = vh;
+                        basis_h[base + 512] = (_Float16)(sc - (float)vh);
                     }
     const int F = cfg->feat_dim;
     // W x 2^e(feature) as f16 hi/lo in B-fragment order; e maps the column maximum into [2^13, 2^14)
@@ -906,7 +911,6 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
     { const char* e = getenv("RADAD_LOGMEL_F32"); h->logmel_f32 = (e && atoi(e) != 0) ? 1 : 0; }
     int rc = put(&h->basis, basis.data(), basis.size() * sizeof(float));
     if (!rc) rc = put((float**)&h->basis_h, basis_h.data(), basis_h.size() * sizeof(_Float16));
-    if (!rc) rc = put((float**)&h->fbfrag_h, fbfrag_h.data(), fbfrag_h.size() * sizeof(_Float16));
     if (!rc) rc = put(&h->fbfrag, fbfrag.data(), fbfrag.size() * sizeof(float));
     if (!rc) rc = put((float**)&h->wfrag_h, wfrag_h.data(), wfrag_h.size() * sizeof(_Float16));
     if (!rc) rc = put(&h->wscale, wscale.data(), wscale.size() * sizeof(float));
@@ -916,7 +920,7 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)logmel_lds_bytes()) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel_h), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)logmel_h_lds_bytes()) != hipSuccess ||
+                                (int)logmel_h_lds_bytes(LH_WG_FRAMES)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)projpool_lds_bytes(8)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -938,7 +942,6 @@ int radad_embed_destroy(radad_embed_t h) {
         DeviceGuard g(h->device);
         if (h->basis) (void)hipFree(h->basis);
         if (h->basis_h) (void)hipFree(h->basis_h);
-        if (h->fbfrag_h) (void)hipFree(h->fbfrag_h);
         if (h->fbfrag) (void)hipFree(h->fbfrag);
         if (h->wfrag_h) (void)hipFree(h->wfrag_h);
         if (h->wscale) (void)hipFree(h->wscale);

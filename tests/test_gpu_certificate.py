@@ -94,7 +94,9 @@ def test_duplicates_and_dense_ties_take_the_exact_kernel(gpu, metric, f16):
     np.testing.assert_allclose(D, od, rtol=1e-6, atol=1e-6)
     assert list(I[7]) == list(range(20000, 20000 + k))   # exact ties: lower ids first
     cert = info["certificate"]
-    assert 2 <= cert["rejected"] <= 6 and cert["rejected_list_used_up"] >= 1 and cert["rejected_buffer_full"] >= 1, info
+    # (a) shows up as a used-up list or as candidates the scan had to drop (which of the two depends on the chunking), (b) as a full buffer
+    assert 2 <= cert["rejected"] <= 6 and cert["rejected_buffer_full"] >= 1, info
+    assert cert["rejected_list_used_up"] + cert["rejected_scan_dropped"] >= 1, info
 
 
 def test_bf16_queries_on_fp16_store(gpu):

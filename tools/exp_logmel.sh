@@ -1,1 +1,6 @@
-for d in 0 1 2 3; do RADAD_DEBUG_LOGMEL=$d python bench.py --steps 5 --warmup 2 --cpu-sample 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('debug', $d, d['kernels_ms'])"; done
+#!/bin/bash
+# log-mel kernel timing experiments (run through gpurun) on the experimental build (make -C .../csrc exp):
+#   RADAD_DEBUG_LOGMEL bits: 1 skip the DFT MFMA loop, 2 skip the segment loads of the prologue, 4 skip the mel MFMAs (results wrong when set)
+export RADAD_HIP_LIB=$GRAFT_REPO_ROOT/radad_retrievalaugmenteddeepfakeaudiodetection_amd/libradad_hip_exp.so
+run() { python bench.py --steps 10 --warmup 3 --cpu-sample 0 --sustain 0 --pcie 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['kernels_ms'])"; }
+for d in 0 1 2 4 6 7; do echo -n "debug $d: "; RADAD_DEBUG_LOGMEL=$d run; done
