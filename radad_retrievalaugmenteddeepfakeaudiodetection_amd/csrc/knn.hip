@@ -832,6 +832,7 @@ struct RefineParams {
     float* out_dist;          // [nq, k]
     int64_t* out_idx;         // [nq, k]
     double* out_key;          // optional [nq, k] float64 distances
+    int debug;                // timing experiments only (-DRADAD_DEBUG_HOOKS, RADAD_DEBUG_KNN): 128 no statistics atomics, 256 no re-score, 512 no ranking, 1024 no fp32 funnel
 };
 
 // One workgroup (256 threads) per query: thread t looks after lists t, t + 256, ... (<= RF_MAXL of them); the k rounds
@@ -840,20 +841,124 @@ struct RefineParams {
 // pass in flight), the ranking is one thread per candidate.
 constexpr int RF_THREADS = 256;
 constexpr int RF_MAXL = 4;               // lists per thread: n_parts <= 1024
+constexpr int RF_STAGE_MAX = 6144;       // list entries per query that k_merge_refine<true> stages in LDS (48 KB + candidates)
 
+constexpr size_t refine_lds_bytes(int cap) { return (size_t)cap * 20 + 256; }      // candidates + per-wave scratch of k_merge_refine
+
+// STAGED (certified mode, n_parts * part_len <= RF_STAGE_MAX): all of the query's list entries are first copied to LDS in ONE
+// round of independent loads, and the k selection rounds, the gathering of everything >= tau and the used-up test run on that
+// copy.  The unstaged form walks the lists in global memory: every round's winner re-reads its list head and every list is
+// walked entry by entry, i.e. 30-50 DEPENDENT trips to L2/HBM per query -- 0.17 ms for 1024 queries that re-score 150 rows
+// each, where the re-scoring itself needs a tenth of that.
+template <bool STAGED>
 __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
-    double* c_key = reinterpret_cast<double*>(smem_m);                   // [cap]
-    int* c_id = reinterpret_cast<int*>(c_key + p.cap);                   // [cap]
+    double* c_key = reinterpret_cast<double*>(smem_m);                   // [cap] float64 distance of a candidate
+    int64_t* c_gid = reinterpret_cast<int64_t*>(c_key + p.cap);          // [cap] its reported id (before id_base)
+    int* c_id = reinterpret_cast<int*>(c_gid + p.cap);                   // [cap] its local row
     float* w_sc = reinterpret_cast<float*>(c_id + p.cap);                // [2][4] per-wave winners of a round (double-buffered)
     int* w_id = reinterpret_cast<int*>(w_sc + 8);                        // [2][4]
     int* w_pt = w_id + 8;                                                // [2][4]
     int* w_cnt = w_pt + 8;                                               // [4] per-wave counts of the append
+    float* e_sc = reinterpret_cast<float*>(smem_m + refine_lds_bytes(p.cap));      // STAGED: [n_parts * part_len] scores ...
+    int* e_id = reinterpret_cast<int*>(e_sc + (STAGED ? p.n_parts * p.part_len : 0));   // ... and rows (-1 - row once selected)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.x;
     const bool cert = p.eps != nullptr;
     const float two_eps = cert ? 2.f * p.eps[q] : 0.f;
     const int64_t qbase = q * p.n_parts;
+    float tau = -INFINITY;
+    int nsel = 0;
+    int why = 0;                             // bit 0: candidate buffer full, 1: a full list used up, 2: admission floor above tau, 3: dropped
+    const float floor_q = (cert && p.thr_init) ? p.thr_init[q] : -INFINITY;     // (read here: off the dependent chain below)
+    const int dropped_q = (cert && p.qflag) ? p.qflag[q] : 0;
+
+  if constexpr (STAGED) {
+    const int NE = p.n_parts * p.part_len;
+    const int64_t ebase = qbase * p.part_len;
+    for (int i = tid; i < NE; i += RF_THREADS) {
+        const int id = p.idx[ebase + i];
+        const float sc = p.score[ebase + i];
+        e_id[i] = id;
+        e_sc[i] = id != IDX_SENTINEL ? sc : -INFINITY;
+    }
+    __syncthreads();
+    // thread t owns entries t, t + 256, ...; it keeps its best unselected entry cached and rescans only after losing it
+    float ls = -INFINITY;
+    int li = IDX_SENTINEL, lp = -1;
+    auto rescan = [&]() {
+        ls = -INFINITY; li = IDX_SENTINEL; lp = -1;
+        for (int i = tid; i < NE; i += RF_THREADS) {
+            const int id = e_id[i];
+            if (id < 0 || id == IDX_SENTINEL) continue;
+            const float sc = e_sc[i];
+            if (lp < 0 || sc > ls || (sc == ls && id < li)) { ls = sc; li = id; lp = i; }
+        }
+    };
+    rescan();
+    const int rounds = min(p.k, p.cap);
+    for (int o = 0; o < rounds; ++o) {
+        float bs = ls;
+        int bi = li, bp = lp;
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) {
+            const float os = __shfl_xor(bs, ofs, 64);
+            const int oi = __shfl_xor(bi, ofs, 64);
+            const int op = __shfl_xor(bp, ofs, 64);
+            if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
+        }
+        const int slot = (o & 1) * 4;
+        if (lane == 0) { w_sc[slot + wave] = bs; w_id[slot + wave] = bi; w_pt[slot + wave] = bp; }
+        __syncthreads();
+        bs = w_sc[slot]; bi = w_id[slot]; bp = w_pt[slot];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float os = w_sc[slot + w];
+            const int oi = w_id[slot + w], op = w_pt[slot + w];
+            if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
+        }
+        if (bp < 0) break;                                   // every list exhausted (block-uniform)
+        if (bp == lp) { e_id[bp] = -1 - bi; rescan(); }      // the owner (bp % 256 == tid) marks it selected
+        if (tid == 0) c_id[nsel] = bi;
+        ++nsel;
+        if (nsel == p.k) tau = bs - two_eps;
+    }
+    __syncthreads();
+    // everything else >= tau, and the used-up test: a FULL list whose last (= smallest) entry is >= tau or selected
+    int cnt = 0, used_up = 0;
+    if (nsel == p.k)
+        for (int i = tid; i < NE; i += RF_THREADS) {
+            const int id = e_id[i];
+            cnt += (id >= 0 && id != IDX_SENTINEL && e_sc[i] >= tau) ? 1 : 0;
+        }
+    for (int l = tid; l < p.n_parts; l += RF_THREADS) {
+        const int last = l * p.part_len + p.part_len - 1;
+        const int id = e_id[last];
+        if (id != IDX_SENTINEL && (id < 0 || e_sc[last] >= tau)) used_up = 1;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) w_cnt[wave] = incl;
+    used_up = __syncthreads_or(used_up);
+    int base_slot = nsel + incl - cnt, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wave) base_slot += w_cnt[w]; total += w_cnt[w]; }
+    if (cnt > 0)
+        for (int i = tid; i < NE; i += RF_THREADS) {
+            const int id = e_id[i];
+            if (id >= 0 && id != IDX_SENTINEL && e_sc[i] >= tau) {
+                if (base_slot < p.cap) c_id[base_slot] = id;
+                ++base_slot;
+            }
+        }
+    nsel += total;
+    if (nsel > p.cap) { nsel = p.cap; why |= 1; }
+    if (used_up) why |= 2;
+  } else {
 
     // cached heads of this thread's lists
     int pos[RF_MAXL];
@@ -871,8 +976,6 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     for (int i = 0; i < RF_MAXL; ++i) { pos[i] = 0; fetch(tid + RF_THREADS * i, 0, hsc[i], hid[i]); }
 
     // 1) the k best by scan score (legacy mode: `cap` of them, and that is all): fixes a_k and tau = a_k - 2 eps
-    float tau = -INFINITY;
-    int nsel = 0;
     const int rounds = cert ? min(p.k, p.cap) : p.cap;
     for (int o = 0; o < rounds; ++o) {
         float bs = -INFINITY;
@@ -908,7 +1011,6 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
         if (cert && nsel == p.k) tau = bs - two_eps;
     }
     if (cert) {
-        int why = 0;                         // bit 0: candidate buffer full, 1: a full list used up, 2: admission floor above tau, 3: dropped
         int cnt = 0, used_up = 0;
         int endp[RF_MAXL];
 #pragma unroll
@@ -955,79 +1057,208 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
         nsel += total;
         if (nsel > p.cap) { nsel = p.cap; why |= 1; }
         if (used_up) why |= 2;
-        if (p.thr_init) {
-            const float fl = p.thr_init[q];
-            if (fl > -INFINITY && !(nsel >= p.k && fl <= tau)) why |= 4;      // rows below the floor are unlisted
-        }
-        if (p.qflag && p.qflag[q]) why |= 8;
+    }
+  }
+    if (cert) {
+        if (floor_q > -INFINITY && !(nsel >= p.k && floor_q <= tau)) why |= 4;      // rows below the floor are unlisted
+        if (dropped_q) why |= 8;
         if (tid == 0) {
             if (why) p.flag_sel[atomicAdd(p.flag_count, 1)] = (int)q;
-            if (p.stats) {
+            if (p.stats && !RADAD_DBG(p.debug, 128)) {
                 atomicAdd(&p.stats[0], nsel);
                 for (int b2 = 0; b2 < 4; ++b2) if (why & (1 << b2)) atomicAdd(&p.stats[1 + b2], 1);
             }
         }
     }
     __syncthreads();                         // c_id complete
-    // 2) float64 re-score: 16 lanes per candidate, 16 candidates per pass, the loads of a pass issued before the first
-    //    multiply (the stored rows are random 2 KB reads: latency-bound unless many are in flight)
-    {
+    // 1b) fp32 funnel (certified mode, more candidates than results): every candidate is scored ONCE in fp32 -- s = q.y, or
+    //     (2q - y).y = |q|^2 - |q - y|^2 for L2 -- together with e = gamma sum |products|, a rigorous bound on that sum's
+    //     rounding error (every term passes through at most dim/16 + 4 fused accumulations; gamma has slack for the
+    //     accumulation of e itself and for forming s -+ e).  A candidate with at least k others CERTAINLY above it
+    //     (s_j - e_j > s_c + e_c) cannot be among the exact k best and is dropped; only the survivors -- k plus the few within
+    //     ~1e-6 of the k-th -- go through the float64 re-score and the ranking, whose cost is linear resp. quadratic in the
+    //     count (with 150 candidates per query they were two thirds of this kernel).
+    if (cert && nsel > p.k && !RADAD_DBG(p.debug, 1024)) {
+        float2* f_lh = reinterpret_cast<float2*>(c_key);                 // (s - e, s + e) per candidate; c_key is free until 2)
+        int* tmp_id = reinterpret_cast<int*>(c_gid);                     // survivors' rows; c_gid is free until 3)
+        const float gamma = (float)(p.dim / 16 + 8) * 5.9604645e-08f * 1.01f;
         const float* qrow = p.q + q * p.dim;
         const int sub = tid >> 4, l16 = tid & 15;
-        for (int c0 = 0; c0 < nsel; c0 += 16) {
-            const int c = c0 + sub;
-            const bool on = c < nsel;
-            const int64_t rid = on ? (int64_t)c_id[c] : 0;
-            double acc = 0.0;
-            for (int i0 = 0; i0 < p.dim; i0 += 512) {                 // 16 lanes x 8 x 4 elements per sweep
-                f32x4 b[8];
+        for (int c0 = 0; c0 < nsel; c0 += 32) {
+            int cc[2];
+            bool on[2];
+            int64_t rid[2];
+            float sdot[2] = {0.f, 0.f}, sabs[2] = {0.f, 0.f};
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int i = i0 + (u * 16 + l16) * 4;
-                    b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (on && i < p.dim) {
-                        if (p.db_f16) {
-                            const f16x4 h4 = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.db) + rid * p.dim + i);
-                            b[u] = f32x4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
-                        } else {
-                            b[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.db) + rid * p.dim + i);
+            for (int h = 0; h < 2; ++h) {
+                cc[h] = c0 + 16 * h + sub;
+                on[h] = cc[h] < nsel;
+                rid[h] = on[h] ? (int64_t)c_id[cc[h]] : 0;
+            }
+            for (int i0 = 0; i0 < p.dim; i0 += 512) {
+                f32x4 b[2][8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + (u * 16 + l16) * 4;
+                        b[h][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (on[h] && i < p.dim) {
+                            if (p.db_f16) {
+                                const f16x4 h4 = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.db) + rid[h] * p.dim + i);
+                                b[h][u] = f32x4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+                            } else {
+                                b[h][u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.db) + rid[h] * p.dim + i);
+                            }
                         }
                     }
-                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int i = i0 + (u * 16 + l16) * 4;
                     if (i < p.dim) {
                         const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + i);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (p.l2) { const double d = (double)a[e] - (double)b[u][e]; acc += d * d; }
-                            else acc += (double)a[e] * (double)b[u][e];
-                        }
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float y = b[h][u][e];
+                                const float x = p.l2 ? 2.f * a[e] - y : a[e];      // (one more rounding per term for L2: inside gamma's slack)
+                                sdot[h] = fmaf(x, y, sdot[h]);
+                                sabs[h] = fmaf(fabsf(x), fabsf(y), sabs[h]);
+                            }
                     }
                 }
             }
 #pragma unroll
-            for (int ofs = 8; ofs > 0; ofs >>= 1) acc += __shfl_xor(acc, ofs, 64);
-            if (on && l16 == 0) c_key[c] = acc;
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int ofs = 8; ofs > 0; ofs >>= 1) {
+                    sdot[h] += __shfl_xor(sdot[h], ofs, 64);
+                    sabs[h] += __shfl_xor(sabs[h], ofs, 64);
+                }
+                if (on[h] && l16 == 0) {
+                    const float e = gamma * sabs[h] + 4.8e-7f * fabsf(sdot[h]);      // + 4 ulp for forming s -+ e
+                    f_lh[cc[h]] = make_float2(sdot[h] - e, sdot[h] + e);
+                }
+            }
+        }
+        __syncthreads();
+        // survivors: fewer than k candidates certainly above (T threads per candidate share the count)
+        const int T = nsel <= 64 ? 4 : (nsel <= 128 ? 2 : 1);
+        const int part = tid & (T - 1);
+        int n_keep = 0;                                                  // survivors so far (block-uniform)
+        for (int c0 = 0; c0 < nsel; c0 += RF_THREADS / T) {
+            const int c = c0 + tid / T;
+            const bool onc = c < nsel;
+            const float hi_c = onc ? f_lh[c].y : 0.f;
+            int above = 0;
+            for (int j = part; j < nsel; j += T) above += (int)(f_lh[j].x > hi_c);
+            if (T >= 2) above += __shfl_xor(above, 1, 64);
+            if (T == 4) above += __shfl_xor(above, 2, 64);
+            const bool keep = onc && part == 0 && !(above >= p.k);       // (NaN scores compare false everywhere: kept)
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) w_cnt[wave] = __popcll(m);
+            __syncthreads();
+            int base = n_keep, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { if (w < wave) base += w_cnt[w]; total += w_cnt[w]; }
+            if (keep) tmp_id[base + __popcll(m & ((1ull << lane) - 1ull))] = c_id[c];
+            n_keep += total;
+            __syncthreads();
+        }
+        for (int c = tid; c < n_keep; c += RF_THREADS) c_id[c] = tmp_id[c];
+        nsel = n_keep;
+        __syncthreads();
+    }
+    // 2) float64 re-score: 16 lanes per candidate, 32 candidates per pass (two per 16-lane group), all row loads of a pass
+    //    issued before the first multiply (the stored rows are random 2 KB reads: latency-bound unless many are in flight)
+    {
+        const float* qrow = p.q + q * p.dim;
+        const int sub = tid >> 4, l16 = tid & 15;
+        for (int c0 = 0; c0 < (RADAD_DBG(p.debug, 256) ? 0 : nsel); c0 += 32) {
+            int cc[2];
+            bool on[2];
+            int64_t rid[2];
+            double acc[2] = {0.0, 0.0};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                cc[h] = c0 + 16 * h + sub;
+                on[h] = cc[h] < nsel;
+                rid[h] = on[h] ? (int64_t)c_id[cc[h]] : 0;
+            }
+            for (int i0 = 0; i0 < p.dim; i0 += 512) {                 // 16 lanes x 8 x 4 elements per sweep
+                f32x4 b[2][8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int i = i0 + (u * 16 + l16) * 4;
+                        b[h][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (on[h] && i < p.dim) {
+                            if (p.db_f16) {
+                                const f16x4 h4 = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.db) + rid[h] * p.dim + i);
+                                b[h][u] = f32x4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+                            } else {
+                                b[h][u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.db) + rid[h] * p.dim + i);
+                            }
+                        }
+                    }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = i0 + (u * 16 + l16) * 4;
+                    if (i < p.dim) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + i);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (p.l2) { const double d = (double)a[e] - (double)b[h][u][e]; acc[h] += d * d; }
+                                else acc[h] += (double)a[e] * (double)b[h][u][e];
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int ofs = 8; ofs > 0; ofs >>= 1) acc[h] += __shfl_xor(acc[h], ofs, 64);
+                if (on[h] && l16 == 0) c_key[cc[h]] = acc[h];
+            }
         }
     }
     __syncthreads();
-    // 3) rank by (distance, id): L2 ascending, IP descending; ids are unique so ranks are a permutation.  One thread per candidate.
-    for (int c = tid; c < nsel; c += RF_THREADS) {
-        const double kc = c_key[c];
-        const int64_t ic = p.id_map ? p.id_map[c_id[c]] : (int64_t)c_id[c];
-        int rank = 0;
-        for (int j = 0; j < nsel; ++j) {
-            const double kj = c_key[j];
-            const int64_t ij = p.id_map ? p.id_map[c_id[j]] : (int64_t)c_id[j];
-            const bool jb = p.l2 ? (kj < kc || (kj == kc && ij < ic)) : (kj > kc || (kj == kc && ij < ic));
-            rank += jb ? 1 : 0;
-        }
-        if (rank < p.k) {
-            p.out_dist[q * p.k + rank] = (float)kc;
-            p.out_idx[q * p.k + rank] = ic + p.id_base;
-            if (p.out_key) p.out_key[q * p.k + rank] = kc;
+    // 3) rank by (distance, id): L2 ascending, IP descending; ids are unique so ranks are a permutation.  Rank = number of
+    //    candidates that come first, counted branch-free over "larger is better" keys by 1, 2 or 4 threads per candidate
+    //    (the first version -- one thread per candidate, short-circuit compares, the id map looked up inside the loop --
+    //    was a third of this kernel's time)
+    const int nrank = RADAD_DBG(p.debug, 512) ? 0 : nsel;
+    for (int c = tid; c < nrank; c += RF_THREADS) {
+        c_gid[c] = p.id_map ? p.id_map[c_id[c]] : (int64_t)c_id[c];
+        if (p.l2) c_key[c] = -c_key[c];
+    }
+    __syncthreads();
+    {
+        const int T = nrank <= 64 ? 4 : (nrank <= 128 ? 2 : 1);
+        const int part = tid & (T - 1);
+        for (int c0 = 0; c0 < nrank; c0 += RF_THREADS / T) {
+            const int c = c0 + tid / T;
+            const bool onc = c < nrank;
+            const double kc = onc ? c_key[c] : 0.0;
+            const int64_t ic = onc ? c_gid[c] : 0;
+            int rank = 0;
+            for (int j = part; j < nrank; j += T) {
+                const double kj = c_key[j];
+                const int64_t ij = c_gid[j];
+                rank += (int)((kj > kc) | ((kj == kc) & (ij < ic)));
+            }
+            if (T >= 2) rank += __shfl_xor(rank, 1, 64);
+            if (T == 4) rank += __shfl_xor(rank, 2, 64);
+            if (onc && part == 0 && rank < p.k) {
+                const double kd = p.l2 ? -kc : kc;
+                p.out_dist[q * p.k + rank] = (float)kd;
+                p.out_idx[q * p.k + rank] = ic + p.id_base;
+                if (p.out_key) p.out_key[q * p.k + rank] = kd;
+            }
         }
     }
     for (int o = nsel + tid; o < p.k; o += RF_THREADS) {   // faiss fills what it cannot find with -1 / +-inf
@@ -1728,6 +1959,9 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         h->count_pending = false;
         if (h->hi_skip == 0 && h->count_nq >= 64 && (int64_t)*h->host_count * 4 > h->count_nq) h->hi_skip = 8;
     }
+#ifdef RADAD_DEBUG_HOOKS
+    if (getenv("RADAD_DEBUG_KNN")) h->hi_skip = 0;     // timing ablations (wrong results, every query rejected): stay on the kernel under test
+#endif
     const bool cert = k <= KNN_CERT_MAX_K;      // beyond: legacy k + margin candidates, no certificate
     const int l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0;
 
@@ -1865,11 +2099,11 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         wp.debug = 0; wp.stamps = nullptr;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (make exp); never in the shipped library
         { const char* dbg = getenv("RADAD_DEBUG_KNN"); wp.debug = dbg ? atoi(dbg) : 0; }
-        {   // RADAD_KNN_STAMPS=<file>: in-kernel s_memtime stamps of waves 0 and 4 of workgroup 0, dumped after the scan (synchronises)
+        {   // RADAD_KNN_STAMPS=<file>: in-kernel s_memtime stamps of the 8 waves of workgroup 0, dumped after the scan (synchronises)
             static unsigned long long* stamp_buf = nullptr;
             if (getenv("RADAD_KNN_STAMPS")) {
-                if (!stamp_buf) (void)hipMalloc(&stamp_buf, 2 * 4096 * 8);
-                (void)hipMemsetAsync(stamp_buf, 0, 2 * 4096 * 8, st);
+                if (!stamp_buf) (void)hipMalloc(&stamp_buf, 8 * 4096 * 8);
+                (void)hipMemsetAsync(stamp_buf, 0, 8 * 4096 * 8, st);
                 wp.stamps = stamp_buf;
             }
         }
@@ -1904,7 +2138,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         h->prof.end(st);
 #ifdef RADAD_DEBUG_HOOKS
         if (wp.stamps) {
-            std::vector<unsigned long long> hs(2 * 4096);
+            std::vector<unsigned long long> hs(8 * 4096);
             (void)hipStreamSynchronize(st);
             (void)hipMemcpy(hs.data(), wp.stamps, hs.size() * 8, hipMemcpyDeviceToHost);
             if (FILE* f = fopen(getenv("RADAD_KNN_STAMPS"), "wb")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
@@ -1963,10 +2197,20 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     m.flag_count = flag_count; m.flag_sel = flag_sel;
     m.db = h->rows; m.db_f16 = h->f16; m.q = q_use; m.id_map = nullptr; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
     m.out_key = out_key_dev;
+    m.debug = 0;
+#ifdef RADAD_DEBUG_HOOKS
+    { const char* dbg = getenv("RADAD_DEBUG_KNN"); m.debug = dbg ? atoi(dbg) : 0; }
+#endif
     m.stats = cert ? flag_count + 1 : nullptr;
     RADAD_REQUIRE(n_splits <= RF_THREADS * RF_MAXL, "radad_knn_search: %d partial lists per query exceed the re-rank kernel's %d", n_splits,
                   RF_THREADS * RF_MAXL);
-    hipLaunchKernelGGL(k_merge_refine, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)cap * 12 + 256, st, m);
+    {   // certified mode with lists that fit the LDS: selection on a staged copy (one round of loads instead of a pointer chase)
+        const size_t entries = (size_t)m.n_parts * m.part_len;
+        if (m.eps && entries <= (size_t)RF_STAGE_MAX)
+            hipLaunchKernelGGL(k_merge_refine<true>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(cap) + entries * 8, st, m);
+        else
+            hipLaunchKernelGGL(k_merge_refine<false>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(cap), st, m);
+    }
     RADAD_HIP_CHECK(hipGetLastError());
 
     // ---- the queries the certificate rejected: exact float64 search, sized and driven by the device-side count ------
