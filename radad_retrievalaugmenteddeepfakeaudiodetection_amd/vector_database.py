@@ -317,6 +317,41 @@ class HipIVFFlatIndex:
         D, I = self.search_device(x, k)
         return D.cpu().numpy(), I.cpu().numpy()
 
+    SNAPSHOT_CHUNK = 1 << 18
+
+    def save(self, path: str):
+        """rows in insertion order as a native flat snapshot at `path` (gathered on the device chunk by chunk into a scratch
+        flat store and streamed out by radad_knn_save: the store never exists in host memory), centroids at path + '.ivf.npz'"""
+        import torch
+        flat = HipFlatIndex(self.d, _lib.METRIC_L2, device=self.device)
+        n = self.ntotal
+        flat.reserve(max(n, 1))
+        for s0 in range(0, n, self.SNAPSHOT_CHUNK):
+            ids = torch.arange(s0, min(n, s0 + self.SNAPSHOT_CHUNK), device=self._dev())
+            flat.add_device(self.reconstruct_batch(ids))
+        flat.save(path)
+        with open(path + ".ivf.npz", "wb") as f:
+            np.savez(f, kind="radad_ivf", centroids=self.centroids(), nlist=self.nlist, ntotal=n)
+
+    def load(self, path: str):
+        """inverse of save(): the centroids are installed as they were, the rows are re-added in insertion order (so ids and list
+        contents come out as before); the snapshot is streamed to the device by radad_knn_load"""
+        import torch
+        z = np.load(path + ".ivf.npz")
+        centroids = z["centroids"]
+        if centroids.shape != (self.nlist, self.d):
+            raise ValueError(f"snapshot has {centroids.shape[0]} lists of dimension {centroids.shape[1]}, index has {self.nlist} x {self.d}")
+        if self.ntotal:
+            raise ValueError("load() needs an empty IVF index")
+        self.set_centroids(centroids)
+        flat = HipFlatIndex(self.d, _lib.METRIC_L2, device=self.device)
+        flat.load(path)
+        if flat.ntotal != int(z["ntotal"]):
+            raise ValueError(f"{path} holds {flat.ntotal} rows, its sidecar says {int(z['ntotal'])}")
+        for s0 in range(0, flat.ntotal, self.SNAPSHOT_CHUNK):
+            ids = torch.arange(s0, min(flat.ntotal, s0 + self.SNAPSHOT_CHUNK), device=self._dev())
+            self.add(flat.reconstruct_batch(ids))
+
     def reconstruct_batch(self, idx):
         import torch
         _lib.require_cuda(idx, "idx")
@@ -504,13 +539,9 @@ class VectorDatabase:
                 logging.warning("No index to save.")
                 return
             if isinstance(self.index, HipIVFFlatIndex):
-                # centroids + rows in insertion order; assignments are recomputed on load (deterministic: nearest centroid)
-                import torch
-                ids = torch.arange(self.index.ntotal, device=torch.device("cuda", self.device_id))
-                rows = np.concatenate([self.index.reconstruct_batch(ids[s0:s0 + (1 << 17)]).cpu().numpy()
-                                       for s0 in range(0, self.index.ntotal, 1 << 17)]) if self.index.ntotal else np.zeros((0, self.index.d), np.float32)
-                with open(self.db_path, "wb") as f:
-                    np.savez(f, kind="radad_ivf", centroids=self.index.centroids(), rows=rows)
+                # rows in insertion order as a NATIVE flat snapshot (streamed from HBM by radad_knn_save, no host copy of the
+                # store), centroids in a small sidecar; assignments are recomputed on load (deterministic: nearest centroid)
+                self.index.save(self.db_path)
             else:
                 self.index.save(self.db_path)
             meta = {"paths": self.vector_paths, "labels": self.vector_labels, "metadata": self.vector_metadata,
@@ -537,7 +568,14 @@ class VectorDatabase:
                 magic = f.read(8)
             if shard is not None and magic != b"RADADKNN":
                 raise ValueError("sharded load is only available for native flat snapshots")
-            if magic[:2] == b"PK":                      # numpy .npz: an IVF store written by save() above
+            if magic == b"RADADKNN" and os.path.exists(self.db_path + ".ivf.npz"):      # an IVF store written by save() above
+                if shard is not None:
+                    raise ValueError("sharded load is only available for flat stores")
+                self.create_index(int(meta["dimension"]))
+                if not isinstance(self.index, HipIVFFlatIndex):
+                    raise ValueError("saved IVF store does not match config (index type)")
+                self.index.load(self.db_path)
+            elif magic[:2] == b"PK":                    # numpy .npz: an IVF store written by an earlier version of save()
                 z = np.load(self.db_path)
                 centroids, rows = z["centroids"], z["rows"]        # NpzFile re-reads an array on every access: read once
                 self.create_index(int(centroids.shape[1]))

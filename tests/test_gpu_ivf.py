@@ -85,7 +85,16 @@ def test_vector_database_ivf_mode(gpu, tmp_path):
     recall = np.mean([len(set(a) & set(b)) / 10 for a, b in zip(I, exact_i)])
     assert recall > 0.9                                              # clustered data, 16 of 64 lists probed
     vdb.save()
+    # the rows travel as a native flat snapshot (streamed, never a host array of the store), the centroids in a sidecar
+    import os
+    with open(vdb.db_path, "rb") as f:
+        assert f.read(8) == b"RADADKNN"
+    assert os.path.exists(vdb.db_path + ".ivf.npz")
     v2 = R.VectorDatabase(cfg)
     v2.load()
     assert v2.index.ntotal == 12000
     np.testing.assert_array_equal(v2.search_batch(q, k=10)[1], I)
+    np.testing.assert_array_equal(v2.index.centroids(), vdb.index.centroids())
+    np.testing.assert_array_equal(v2.index.assignments(), vdb.index.assignments())
+    for i in (0, 1, 5999, 11999):
+        np.testing.assert_array_equal(v2.index.reconstruct(i), db[i])

@@ -3,8 +3,9 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 T=$1
-bash tools/profile_stats.sh ${T} > /dev/null 2>&1
-bash tools/profile_r1.sh ${T} > gpurun_out/pmc_${T}.out 2>&1
+echo stats; timeout -k 10 300 bash tools/profile_stats.sh ${T} > /dev/null 2>&1
+echo pmc; timeout -k 10 600 bash tools/profile_r1.sh ${T} > gpurun_out/pmc_${T}.out 2>&1
+echo benches
 python bench.py > gpurun_out/${T}_bench_default.json 2> gpurun_out/${T}_bench_default.err
 python bench.py --workload ragged --pcie 0 > gpurun_out/${T}_bench_ragged.json 2> /dev/null
 python bench.py --store-dtype f16 --cpu-baseline-clips 0 --pcie 0 --sustain 0 > gpurun_out/${T}_bench_f16.json 2> /dev/null
