@@ -308,7 +308,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
     constexpr int PP_THREADS = PP_WAVES * 64;
     constexpr int PP_FEATS = PP_WAVES * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // the frame projection runs on the f16 matrix pipe in split form (see knn_wide.inc): the staged log-mel frames are two
+    // the frame projection runs on the f16 matrix pipe in split form: the staged log-mel frames are two
     // f16 planes (hi, lo of v 2^12), W comes pre-split per feature with a power-of-two column scale
     _Float16* slm_h = reinterpret_cast<_Float16*>(smem);     // [PP_FB][PP_LDH]
     _Float16* slm_l = slm_h + PP_FB * PP_LDH;                // [PP_FB][PP_LDH]
