@@ -36,6 +36,9 @@ void radad_set_error(const char* fmt, ...);
 #endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// the same four floats behind a pointer that is only dword-aligned (a segment of a clip that starts at an arbitrary sample):
+// global_load_dwordx4 needs no more than that on gfx9+
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));

@@ -113,14 +113,13 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
     const int nv = L >> 2;                                                  // L % 160 == 0
     f32x4 raw[UNR];
     {
-        const bool vec_ok = (reinterpret_cast<uintptr_t>(src) & 15) == 0;
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int i4 = u * LM_THREADS + tid;
             const int i = i4 * 4;
             f32x4 t = {0.f, 0.f, 0.f, 0.f};
             if (i4 < nv && !RADAD_DBG(p.debug, 2)) {
-                if (vec_ok && i + 4 <= valid) t = *reinterpret_cast<const f32x4*>(src + i);
+                if (i + 4 <= valid) t = *reinterpret_cast<const f32x4_a4*>(src + i);     // (dword alignment is all a 128-bit load needs)
                 else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) t[e] = i + e < valid ? src[i + e] : 0.f;
