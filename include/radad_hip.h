@@ -185,7 +185,9 @@ int radad_ivf_centroids(radad_ivf_t h, float* out_dev, void* stream);
 int radad_ivf_assignments_host(radad_ivf_t h, int32_t* out_host, int64_t cap);
 int radad_ivf_add(radad_ivf_t h, const float* rows_dev, int64_t n, void* stream);               /* synchronous */
 int radad_ivf_search(radad_ivf_t h, const float* q_dev, int64_t nq, int k, int nprobe, float* out_dist_dev,
-                     int64_t* out_idx_dev, void* stream);                                         /* synchronous */
+                     int64_t* out_idx_dev, void* stream);      /* asynchronous on `stream` (the (query, probe) pairs are grouped by list on
+                                                                    the device); only the first search after an add rebuilds the list layout
+                                                                    synchronously */
 int radad_ivf_reconstruct(radad_ivf_t h, const int64_t* idx_dev, int64_t n, float* out_dev, void* stream);
 
 /* row L2 normalisation x / (|x| + 1e-12)  (vector_database.py:100-105); in-place allowed */
