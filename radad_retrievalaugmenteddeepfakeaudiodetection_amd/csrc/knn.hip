@@ -861,7 +861,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     int* w_pt = w_id + 8;                                                // [2][4]
     int* w_cnt = w_pt + 8;                                               // [4] per-wave counts of the append
     float* e_sc = reinterpret_cast<float*>(smem_m + refine_lds_bytes(p.cap));      // STAGED: [n_parts * part_len] scores ...
-    int* e_id = reinterpret_cast<int*>(e_sc + (STAGED ? p.n_parts * p.part_len : 0));   // ... and rows (-1 - row once selected)
+    int* e_id = reinterpret_cast<int*>(e_sc + (STAGED ? p.n_parts * p.part_len : 0));   // ... and rows; then the radix select's 256 bins
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.x;
     const bool cert = p.eps != nullptr;
@@ -876,65 +876,65 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
   if constexpr (STAGED) {
     const int NE = p.n_parts * p.part_len;
     const int64_t ebase = qbase * p.part_len;
+    int* hist = e_id + NE;                                               // [256] digit histogram of the radix select
     for (int i = tid; i < NE; i += RF_THREADS) {
         const int id = p.idx[ebase + i];
         const float sc = p.score[ebase + i];
         e_id[i] = id;
         e_sc[i] = id != IDX_SENTINEL ? sc : -INFINITY;
     }
-    __syncthreads();
-    // thread t owns entries t, t + 256, ...; it keeps its best unselected entry cached and rescans only after losing it
-    float ls = -INFINITY;
-    int li = IDX_SENTINEL, lp = -1;
-    auto rescan = [&]() {
-        ls = -INFINITY; li = IDX_SENTINEL; lp = -1;
+    // a_k = the k-th largest scan score, by a 4-pass radix select on the order-preserving image of the float bits (sentinels are
+    // -inf, the smallest key).  Only the VALUE is needed: every entry >= tau = a_k - 2 eps is re-scored, the k best among them;
+    // the first version found the k best one by one (k rounds of a block-wide arg-max, two barriers each: 40 % of this kernel).
+    auto okey = [](float v) { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+    unsigned prefix = 0, pmask = 0;
+    int krem = p.k;
+    bool have_k = NE >= p.k;                                             // (block-uniform)
+    for (int shift = 24; shift >= 0 && have_k; shift -= 8) {
+        hist[tid] = 0;                                                   // RF_THREADS == 256 bins
+        __syncthreads();                                                 // (first pass: also publishes e_sc / e_id)
         for (int i = tid; i < NE; i += RF_THREADS) {
-            const int id = e_id[i];
-            if (id < 0 || id == IDX_SENTINEL) continue;
-            const float sc = e_sc[i];
-            if (lp < 0 || sc > ls || (sc == ls && id < li)) { ls = sc; li = id; lp = i; }
+            const unsigned key = okey(e_sc[i]);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
         }
-    };
-    rescan();
-    const int rounds = min(p.k, p.cap);
-    for (int o = 0; o < rounds; ++o) {
-        float bs = ls;
-        int bi = li, bp = lp;
-#pragma unroll
-        for (int ofs = 32; ofs > 0; ofs >>= 1) {
-            const float os = __shfl_xor(bs, ofs, 64);
-            const int oi = __shfl_xor(bi, ofs, 64);
-            const int op = __shfl_xor(bp, ofs, 64);
-            if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
-        }
-        const int slot = (o & 1) * 4;
-        if (lane == 0) { w_sc[slot + wave] = bs; w_id[slot + wave] = bi; w_pt[slot + wave] = bp; }
         __syncthreads();
-        bs = w_sc[slot]; bi = w_id[slot]; bp = w_pt[slot];
+        if (wave == 0) {                                                 // the digit that holds the krem-th largest matching key
+            int c[4];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float os = w_sc[slot + w];
-            const int oi = w_id[slot + w], op = w_pt[slot + w];
-            if (op >= 0 && (bp < 0 || os > bs || (os == bs && oi < bi))) { bs = os; bi = oi; bp = op; }
+            for (int j = 0; j < 4; ++j) c[j] = hist[4 * lane + j];
+            const int s4 = c[0] + c[1] + c[2] + c[3];
+            int incl = s4;                                               // matching keys in this lane's bins and all higher ones
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_down(incl, o, 64);
+                if (lane + o < 64) incl += t;
+            }
+            int above = incl - s4;
+            if (above < krem && krem <= incl) {                          // exactly one lane
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    if (above + c[j] >= krem) { w_pt[0] = 4 * lane + j; w_pt[1] = krem - above; break; }
+                    above += c[j];
+                }
+            }
         }
-        if (bp < 0) break;                                   // every list exhausted (block-uniform)
-        if (bp == lp) { e_id[bp] = -1 - bi; rescan(); }      // the owner (bp % 256 == tid) marks it selected
-        if (tid == 0) c_id[nsel] = bi;
-        ++nsel;
-        if (nsel == p.k) tau = bs - two_eps;
+        __syncthreads();
+        prefix |= (unsigned)w_pt[0] << shift;
+        pmask |= 255u << shift;
+        krem = w_pt[1];
     }
-    __syncthreads();
-    // everything else >= tau, and the used-up test: a FULL list whose last (= smallest) entry is >= tau or selected
+    if (!have_k) __syncthreads();                                        // publishes e_sc / e_id
+    if (have_k) {
+        const unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+        const float a_k = __uint_as_float(u);
+        if (a_k > -INFINITY) tau = a_k - two_eps;                        // (fewer than k listed rows: tau stays -inf, all of them go on)
+    }
+    // everything >= tau goes on to the re-score; the used-up test: a FULL list whose last (= smallest) entry is >= tau
     int cnt = 0, used_up = 0;
-    if (nsel == p.k)
-        for (int i = tid; i < NE; i += RF_THREADS) {
-            const int id = e_id[i];
-            cnt += (id >= 0 && id != IDX_SENTINEL && e_sc[i] >= tau) ? 1 : 0;
-        }
+    for (int i = tid; i < NE; i += RF_THREADS) cnt += (e_id[i] != IDX_SENTINEL && e_sc[i] >= tau) ? 1 : 0;
     for (int l = tid; l < p.n_parts; l += RF_THREADS) {
         const int last = l * p.part_len + p.part_len - 1;
-        const int id = e_id[last];
-        if (id != IDX_SENTINEL && (id < 0 || e_sc[last] >= tau)) used_up = 1;
+        if (e_id[last] != IDX_SENTINEL && e_sc[last] >= tau) used_up = 1;
     }
     int incl = cnt;
 #pragma unroll
@@ -944,18 +944,18 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     }
     if (lane == 63) w_cnt[wave] = incl;
     used_up = __syncthreads_or(used_up);
-    int base_slot = nsel + incl - cnt, total = 0;
+    int base_slot = incl - cnt, total = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) { if (w < wave) base_slot += w_cnt[w]; total += w_cnt[w]; }
     if (cnt > 0)
         for (int i = tid; i < NE; i += RF_THREADS) {
             const int id = e_id[i];
-            if (id >= 0 && id != IDX_SENTINEL && e_sc[i] >= tau) {
+            if (id != IDX_SENTINEL && e_sc[i] >= tau) {
                 if (base_slot < p.cap) c_id[base_slot] = id;
                 ++base_slot;
             }
         }
-    nsel += total;
+    nsel = total;
     if (nsel > p.cap) { nsel = p.cap; why |= 1; }
     if (used_up) why |= 2;
   } else {
@@ -2207,7 +2207,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     {   // certified mode with lists that fit the LDS: selection on a staged copy (one round of loads instead of a pointer chase)
         const size_t entries = (size_t)m.n_parts * m.part_len;
         if (m.eps && entries <= (size_t)RF_STAGE_MAX)
-            hipLaunchKernelGGL(k_merge_refine<true>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(cap) + entries * 8, st, m);
+            hipLaunchKernelGGL(k_merge_refine<true>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(cap) + entries * 8 + 1024, st, m);
         else
             hipLaunchKernelGGL(k_merge_refine<false>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(cap), st, m);
     }
