@@ -131,6 +131,13 @@ int radad_knn_snapshot_info(const char* path, int* dim_out, int* metric_out, int
 /* seconds spent in the most recent search's kernels are NOT measured here; use HIP events on `stream`.
  * Query the launch geometry of the last search (for roofline accounting in bench.py). */
 int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, int* block_threads);
+/* which scan kernel the last search ran: what it streams decides the bytes a roofline is quoted on */
+#define RADAD_SCAN_F32_TILE 0     /* fp32-MFMA tile kernels (fp32 rows; also the generic kernel) */
+#define RADAD_SCAN_HI_TILE 1      /* certified f16-MFMA tile scan over the f16 plane / fp16 store (more than 16 queries) */
+#define RADAD_SCAN_F32_SMALLQ 2   /* <= 16 queries, fp32 rows streamed (4 bytes per element) */
+#define RADAD_SCAN_HI_SMALLQ 3    /* <= 16 queries, f16 plane / fp16 store streamed (2 bytes per element), certified */
+#define RADAD_SCAN_F16_TILE 4     /* fp16 store on the fp16-MFMA tile kernel without the certificate path */
+int radad_knn_last_scan_kind(radad_knn_t h, int* kind);
 /* Certificate of the most recent search (see radad_knn_search_f64): number of queries the float64 re-rank could NOT certify
  * and that were therefore searched again by the exact float64 kernel (results are exact either way).  Synchronises with
  * that search.  radad_knn_last_certificate additionally returns the batch size and stats6 = {rejected queries, sum over

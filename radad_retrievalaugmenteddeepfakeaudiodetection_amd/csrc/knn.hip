@@ -784,6 +784,131 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_f32_smallq(SmallQParams p
     }
 }
 
+// ---- the same small-batch scan over the f16 plane (certified mode) -----------------------------------------------------
+// Half the bytes: the hi plane of an fp32 store (or an fp16 store itself) is streamed instead of the fp32 rows, one
+// v_mfma_f32_16x16x32_f16 per 32 elements of 16 rows against the f16-rounded queries in LDS.  The scores carry the error bound
+// eps(q) of the certified scan (k_hi_rows), and k_merge_refine certifies or rejects every query exactly as it does for the
+// tile kernel (complete top-(k + margin) lists per workgroup, no admission floor): the online search reads 1 GB instead of 2.
+struct SmallQHiParams {
+    const _Float16* db;         // [n][dim] f16 rows
+    const float* rscale;        // [n] per-row scale, or nullptr: uscale for every row
+    float uscale;
+    const float* ynorm;         // [n] |y|^2 (L2)
+    const _Float16* q;          // [nq][dim] f16 queries (scaled per query)
+    const float* qscale;        // [nq]
+    int64_t n;
+    int nq, dim, k, l2;
+    int rows_per_wave;          // multiple of 16
+    int n_parts;                // workgroups = lists per query
+    float* part_score; int* part_idx;   // [nq, n_parts, k]
+};
+
+template <int KSEL>
+__global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int qld = p.dim + 8;                                    // padded query row (halfs): 16-byte chunks of the 16 rows fall in distinct banks
+    _Float16* sQ = reinterpret_cast<_Float16*>(smem);             // [16][dim + 8]
+    float2* sCand = reinterpret_cast<float2*>(sQ + SQ_NQ * qld);  // [4 waves][16 q][SQ_SLOTS]
+    int* sCnt = reinterpret_cast<int*>(sCand + 4 * SQ_NQ * 24);   // [4 waves][16]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    for (int i = tid; i < SQ_NQ * (p.dim >> 3); i += SQ_THREADS) {
+        const int qq = i / (p.dim >> 3), c8 = i % (p.dim >> 3);
+        f16x8 v = {};
+        if (qq < p.nq) v = *reinterpret_cast<const f16x8*>(p.q + (int64_t)qq * p.dim + c8 * 8);
+        *reinterpret_cast<f16x8*>(sQ + qq * qld + c8 * 8) = v;
+    }
+    if (tid < 4 * SQ_NQ) sCnt[tid] = 0;
+    __syncthreads();
+
+    const int part = blockIdx.x * 4 + wave;      // this wave's slice of the store
+    const int64_t w_begin = (int64_t)part * p.rows_per_wave;
+    const int64_t w_end = min(w_begin + p.rows_per_wave, p.n);
+    float2* myCand = sCand + wave * SQ_NQ * SQ_SLOTS;
+    int* myCnt = sCnt + wave * SQ_NQ;
+
+    const u64 SENT = pack_key(-INFINITY, IDX_SENTINEL);
+    u64 lst[KSEL];                       // meaningful in lanes 0..15 (lane = query)
+#pragma unroll
+    for (int j = 0; j < KSEL; ++j) lst[j] = SENT;
+    float thr = -INFINITY;               // threshold of query (lane & 15), refreshed from the owner lane
+    const float qs = r16 < p.nq ? p.qscale[r16] : 0.f;
+    // lane (r16, g) holds elements 32 kb + 8 g .. + 7 of row r16 (A) and of query r16 (B): one load instruction reads 64
+    // contiguous bytes of each of its 16 rows, two consecutive ones a whole 128-byte line
+    const _Float16* qrow = sQ + r16 * qld + 8 * g;
+    const int nkb = p.dim >> 5;
+
+    for (int64_t row0 = w_begin; row0 < w_end; row0 += 16) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};       // even / odd K blocks: two MFMA chains
+        const int64_t ra = min(row0 + r16, p.n - 1);                             // clamp: masked below
+        const _Float16* pa = p.db + ra * p.dim + 8 * g;
+        float rs[4], yn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t row = min(row0 + 4 * g + e, p.n - 1);
+            rs[e] = p.rscale ? p.rscale[row] : p.uscale;
+            yn[e] = p.l2 ? p.ynorm[row] : 0.f;
+        }
+        constexpr int PKB = KSEL <= 16 ? 16 : 8;      // K blocks per panel (the 32-entry lists leave fewer registers)
+        for (int kp = 0; kp < nkb; kp += PKB) {
+            const int nb = min(PKB, nkb - kp);
+            f16x8 v[PKB];
+#pragma unroll
+            for (int kb = 0; kb < PKB; ++kb)
+                if (kb < nb) v[kb] = *reinterpret_cast<const f16x8*>(pa + (kp + kb) * 32);
+#pragma unroll
+            for (int kb = 0; kb < PKB; ++kb)
+                if (kb < nb) {
+                    const f16x8 b = *reinterpret_cast<const f16x8*>(qrow + (kp + kb) * 32);
+                    if (kb & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[kb], b, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[kb], b, acc0, 0, 0, 0);
+                }
+        }
+        // acc0[e] + acc1[e]: row row0 + 4g + e, query r16
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t row = row0 + 4 * g + e;
+            float sc = (acc0[e] + acc1[e]) * rs[e] * qs;
+            if (p.l2) sc = 2.f * sc - yn[e];
+            if (row < w_end && r16 < p.nq && sc >= thr) {
+                const int sl = atomicAdd(&myCnt[r16], 1);          // < SQ_SLOTS by construction (4 x 4 lanes)
+                myCand[r16 * SQ_SLOTS + sl] = make_float2(sc, __int_as_float((int)row));
+                any = true;
+            }
+        }
+        if (__any(any)) {                                              // wave-uniform; LDS ops of one wave are ordered
+            if (lane < SQ_NQ) {
+                const int c = myCnt[lane];
+                for (int i = 0; i < c; ++i) {
+                    const float2 cv = myCand[lane * SQ_SLOTS + i];
+                    list_insert<KSEL>(lst, pack_key(cv.x, __float_as_int(cv.y)));
+                }
+                myCnt[lane] = 0;
+            }
+            thr = __shfl(key_score(lst[KSEL - 1]), r16, 64);
+        }
+    }
+    // one list per WORKGROUP leaves the kernel: waves 1-3 hand their lists to wave 0 through the slot buffer
+    __syncthreads();
+    u64* sKeys = reinterpret_cast<u64*>(sCand);                     // [3][16][KSEL] (<= the slot buffer's 16 KB)
+    if (wave > 0 && lane < SQ_NQ) {
+#pragma unroll
+        for (int j = 0; j < KSEL; ++j) sKeys[((wave - 1) * SQ_NQ + lane) * KSEL + j] = lst[j];
+    }
+    __syncthreads();
+    if (wave == 0 && lane < p.nq) {
+        for (int w = 0; w < 3; ++w)
+            for (int j = 0; j < KSEL; ++j) list_insert<KSEL>(lst, sKeys[(w * SQ_NQ + lane) * KSEL + j]);
+        float* ls = p.part_score + ((int64_t)lane * p.n_parts + blockIdx.x) * p.k;
+        int* li = p.part_idx + ((int64_t)lane * p.n_parts + blockIdx.x) * p.k;
+#pragma unroll
+        for (int j = 0; j < KSEL; ++j)
+            if (j < p.k) { ls[j] = key_score(lst[j]); li[j] = key_id(lst[j]); }
+    }
+}
+
 constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float2) * KT_N * CAND_CAP + sizeof(float) * KT_N + sizeof(int) * KT_N + 16; }
 
 // ---- merge of sorted partial lists -----------------------------------------------------------------------
@@ -1648,6 +1773,7 @@ struct radad_knn_s {
     void* ws = nullptr;
     size_t ws_bytes = 0;
     int last_qtiles = 0, last_splits = 0, last_threads = KNN_THREADS;
+    int last_kind = RADAD_SCAN_F32_TILE;   // which scan kernel the last search ran (radad_knn_last_scan_kind)
     EventRing prof;
     std::mutex mu;
 };
@@ -1989,9 +2115,15 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     }
     if (!use_hi && cert && !knn_ensure_hi(h, st, false)) { radad_set_error("store statistics could not be computed"); return RADAD_EHIP; }
     const int ksel = k + margin;                 // list length of the fp32 tile kernels
-    const bool smallq = !use_hi && !h->f16 && nq <= SQ_NQ && h->dim % 32 == 0 && h->dim <= SQ_MAX_DIM && ksel <= 32 && h->ntotal > 0;
+    const bool smallq_geom = !use_hi && nq <= SQ_NQ && h->dim <= SQ_MAX_DIM && ksel <= 32 && h->ntotal > 0;
+    // the small batch over the f16 plane (certified like the tile scan): stores the plane is kept for, or fp16 stores
+    static const int smallq_hi_on = [] { const char* e = getenv("RADAD_KNN_SMALLQ_HI"); return e ? atoi(e) : 1; }();
+    bool smallq_hi = false;
+    if (smallq_geom && cert && smallq_hi_on && h->dim % 64 == 0 && h->ntotal >= 16384 && !h->hi_off && h->hi_skip == 0)
+        smallq_hi = knn_ensure_hi(h, st, true);
+    const bool smallq = smallq_geom && !smallq_hi && !h->f16 && h->dim % 32 == 0;
     int sq_rows_per_wave = 0;
-    if (smallq) {
+    if (smallq || smallq_hi) {
         const int64_t waves_wanted = 256 * 8;                                     // 8 waves (2 workgroups) per CU
         int64_t rpw = ceil_div64(ceil_div64(h->ntotal, waves_wanted), 16) * 16;
         rpw = std::max<int64_t>(rpw, 128);
@@ -1999,9 +2131,11 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         n_splits = (int)ceil_div64(ceil_div64(h->ntotal, rpw), 4);                // workgroups of 4 waves = lists per query
         n_qtiles = 1;
     }
-    const bool f16_tile = !use_hi && h->f16 && ksel <= 32 && h->dim % 64 == 0;
+    const bool f16_tile = !use_hi && !smallq_hi && h->f16 && ksel <= 32 && h->dim % 64 == 0;
     h->last_qtiles = n_qtiles;
-    h->last_threads = use_hi ? KW_THREADS : (smallq ? SQ_THREADS : KNN_THREADS);
+    h->last_threads = use_hi ? KW_THREADS : ((smallq || smallq_hi) ? SQ_THREADS : KNN_THREADS);
+    h->last_kind = use_hi ? RADAD_SCAN_HI_TILE : smallq_hi ? RADAD_SCAN_HI_SMALLQ : smallq ? RADAD_SCAN_F32_SMALLQ
+                          : f16_tile ? RADAD_SCAN_F16_TILE : RADAD_SCAN_F32_TILE;
     h->last_splits = n_splits;
     const int plen = use_hi ? KW_LIST : ksel;    // entries of a partial list
     const int cap = cert ? std::max(k + KNN_CERT_EXTRA, KNN_CERT_CAP) : ksel;
@@ -2012,7 +2146,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     const size_t qrow_f32 = al256((size_t)nq * h->dim * sizeof(float));
     const size_t b_qf = q_dtype == RADAD_Q_BF16 ? qrow_f32 : 0;
     const size_t b_qn = h->metric == RADAD_METRIC_COSINE ? qrow_f32 : 0;
-    const size_t b_qh = (use_hi || f16_tile) ? al256((size_t)nq * h->dim * 2) : 0;
+    const size_t b_qh = (use_hi || f16_tile || smallq_hi) ? al256((size_t)nq * h->dim * 2) : 0;
     const size_t b_vec = al256((size_t)nq * sizeof(float));
     const size_t part_elems = (size_t)nq * std::max<size_t>((size_t)n_splits * plen, use_hi ? (size_t)KW_SAMPLE_SPLITS * 16 : 0);
     const size_t b_part = al256(part_elems * sizeof(float));
@@ -2057,6 +2191,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)ceil_div64(ne, 1024)), dim3(256), 0, st, (const unsigned short*)q_in, qf, ne);
         q_use = qf;
     }
+    const bool hi_q = use_hi || smallq_hi;                 // f16 queries with a per-query scale
     const bool prep = cert || use_hi || f16_tile;          // k_hi_rows runs: it also normalises and clears the flags
     if (h->metric == RADAD_METRIC_COSINE) {
         float* qn = (float*)(ws + o_qn);
@@ -2067,12 +2202,12 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     if (prep) {
         HiRowsParams hp;
         hp.in = q_use; hp.in_f16 = 0;
-        hp.hi = (use_hi || f16_tile) ? qh : nullptr;
-        hp.scale_out = use_hi ? qscale : nullptr;
+        hp.hi = (hi_q || f16_tile) ? qh : nullptr;
+        hp.scale_out = hi_q ? qscale : nullptr;
         hp.stat_max = nullptr; hp.eps_out = cert ? eps : nullptr; hp.ystat = h->stat;
         hp.n = nq; hp.dim = h->dim;
-        hp.fixed_e = use_hi ? HI_E_PER_ROW : 0;          // the fp16 tile kernel multiplies un-scaled fp16 queries
-        hp.l2 = l2; hp.exact_ops = (use_hi || f16_tile) ? 0 : 1;
+        hp.fixed_e = hi_q ? HI_E_PER_ROW : 0;            // the fp16 tile kernel multiplies un-scaled fp16 queries
+        hp.l2 = l2; hp.exact_ops = (hi_q || f16_tile) ? 0 : 1;
         hp.norm_out = h->metric == RADAD_METRIC_COSINE ? (float*)(ws + o_qn) : nullptr;
         hp.zero_flags = cert ? qflag : nullptr; hp.zero_counters = cert ? flag_count : nullptr;
         hipLaunchKernelGGL(k_hi_rows, dim3(rgrid), dim3(256), 0, st, hp);
@@ -2144,6 +2279,29 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
             if (FILE* f = fopen(getenv("RADAD_KNN_STAMPS"), "wb")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
         }
 #endif
+    } else if (smallq_hi) {
+        SmallQHiParams sp;
+        sp.db = h->f16 ? (const _Float16*)h->rows : h->hi;
+        sp.rscale = h->f16 ? nullptr : h->rscale;
+        sp.uscale = (!h->f16 && h->metric == RADAD_METRIC_COSINE) ? 0x1p-14f : 1.0f;
+        sp.ynorm = h->ynorm; sp.q = qh; sp.qscale = qscale; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel; sp.l2 = l2;
+        sp.rows_per_wave = sq_rows_per_wave; sp.n_parts = n_splits; sp.part_score = ps; sp.part_idx = pi;
+        const size_t slot_bytes = std::max<size_t>(sizeof(float2) * 4 * SQ_NQ * SQ_SLOTS, sizeof(u64) * 3 * SQ_NQ * 32);
+        const size_t lds = sizeof(_Float16) * SQ_NQ * (h->dim + 8) + slot_bytes + sizeof(int) * 4 * SQ_NQ;
+        const dim3 sgrid((unsigned)n_splits);
+        if (ksel <= 16) {
+            RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_hi_smallq<16>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            h->prof.begin(st);
+            hipLaunchKernelGGL(k_knn_hi_smallq<16>, sgrid, dim3(SQ_THREADS), lds, st, sp);
+            h->prof.end(st);
+        } else {
+            RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_hi_smallq<32>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            h->prof.begin(st);
+            hipLaunchKernelGGL(k_knn_hi_smallq<32>, sgrid, dim3(SQ_THREADS), lds, st, sp);
+            h->prof.end(st);
+        }
     } else if (smallq) {
         SmallQParams sp;
         sp.db = (const float*)h->rows; sp.ynorm = h->ynorm; sp.q = q_use; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel;
@@ -2347,6 +2505,12 @@ int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, i
     if (n_query_tiles) *n_query_tiles = h->last_qtiles;
     if (n_db_splits) *n_db_splits = h->last_splits;
     if (block_threads) *block_threads = h->last_threads;
+    return RADAD_OK;
+}
+
+int radad_knn_last_scan_kind(radad_knn_t h, int* kind) {
+    RADAD_REQUIRE(h && kind, "NULL argument");
+    *kind = h->last_kind;
     return RADAD_OK;
 }
 

@@ -173,7 +173,10 @@ class HipFlatIndex:
         _lib.check(self._lib.radad_knn_last_launch(self._h, C.byref(a), C.byref(b), C.byref(c)))
         st, nq = (C.c_int * 6)(), C.c_int64()
         _lib.check(self._lib.radad_knn_last_certificate(self._h, C.byref(nq), st))
+        kind = C.c_int()
+        _lib.check(self._lib.radad_knn_last_scan_kind(self._h, C.byref(kind)))
         return {"query_tiles": a.value, "db_splits": b.value, "block_threads": c.value, "rechecked_queries": st[0],
+                "scan_kind": ("f32_tile", "hi_tile", "f32_smallq", "hi_smallq", "f16_tile")[kind.value],
                 "certificate": {"queries": nq.value, "rejected": st[0], "candidates_rescored": st[1],
                                 "rejected_buffer_full": st[2], "rejected_list_used_up": st[3],
                                 "rejected_floor_above_threshold": st[4], "rejected_scan_dropped": st[5]}}

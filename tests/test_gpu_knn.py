@@ -510,3 +510,40 @@ def test_knn_truncated_lists_recheck(gpu, metric):
     D10, I10 = idx.search(q, 10)
     np.testing.assert_array_equal(I10, oi[:, :10])
     assert idx.last_launch()["rechecked_queries"] <= len(clustered) + 12
+
+
+@pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
+@pytest.mark.parametrize("f16", [False, True])
+def test_small_batch_on_the_f16_plane(gpu, monkeypatch, metric, f16):
+    """<= 16 queries on a store of >= 16384 rows stream the f16 plane (k_knn_hi_smallq) and are certified like the tile scan; the
+    same store with the plane switched off (RADAD_KNN_HI=0 at creation) streams the fp32 rows: both are the float64 brute force."""
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    m = {"L2": _lib.METRIC_L2, "IP": _lib.METRIC_IP, "COSINE": _lib.METRIC_COSINE}[metric]
+    n, dim, k = 40000, 128, 15
+    db = synth.rows(0, n, dim, 8801)
+    q = synth.rows(0, 16, dim, 8802)
+    for j in range(16):
+        db[(j * 2003 + 9) % n] = q[j] + np.float32(0.03) * synth.rows(j, 1, dim, 8803)[0]
+    idx = HipFlatIndex(dim, m, 0, store_f16=f16)
+    idx.add(db)
+    monkeypatch.setenv("RADAD_KNN_HI", "0")
+    ref = HipFlatIndex(dim, m, 0, store_f16=f16)
+    monkeypatch.delenv("RADAD_KNN_HI")
+    ref.add(db)
+    for nq in (1, 5, 16):
+        D, I = idx.search(q[:nq], k)
+        assert idx.last_launch()["scan_kind"] == "hi_smallq"
+        Dr, Ir = ref.search(q[:nq], k)
+        assert ref.last_launch()["scan_kind"] in ("f32_smallq", "f16_tile")
+        np.testing.assert_array_equal(I, Ir)
+        np.testing.assert_allclose(D, Dr, rtol=1e-6, atol=1e-6)
+        assert idx.last_launch()["certificate"]["queries"] == nq
+    import torch
+    stored = idx.reconstruct_batch(torch.arange(n, device=gpu)).cpu().numpy().astype(np.float32)
+    if metric == "COSINE":
+        qt = torch.from_numpy(q).to(gpu); qo = torch.empty_like(qt)
+        _lib.check(_lib.load().radad_rownorm(qt.data_ptr(), qo.data_ptr(), 16, dim, 0, _lib.stream_ptr(gpu)))
+        _, oi = O.knn(stored, qo.cpu().numpy(), k, "IP")
+    else:
+        _, oi = O.knn(stored, q, k, metric)
+    np.testing.assert_array_equal(idx.search(q, k)[1], oi)
