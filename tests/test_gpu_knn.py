@@ -547,3 +547,36 @@ def test_small_batch_on_the_f16_plane(gpu, monkeypatch, metric, f16):
     else:
         _, oi = O.knn(stored, q, k, metric)
     np.testing.assert_array_equal(idx.search(q, k)[1], oi)
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "L2"])
+def test_full_size_properties(gpu, metric):
+    """BASELINE's store size (1 M x 512) through size-independent properties: every stored row retrieves ITSELF first (distance 0 /
+    similarity 1), lists are sorted, ids are distinct and in range, a second search gives the same bits, and the certificate
+    rejects nothing on this data."""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    lib = _lib.load()
+    n, dim, k, nq = 1_000_000, 512, 10, 2048
+    m = {"L2": _lib.METRIC_L2, "COSINE": _lib.METRIC_COSINE}[metric]
+    rows = torch.empty((n, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(rows.data_ptr(), 0, n, dim, 777, 0, _lib.stream_ptr(gpu)))
+    idx = HipFlatIndex(dim, m, 0)
+    idx.reserve(n)
+    idx.add_device(rows)
+    pick = (torch.arange(nq, device=gpu) * 487 + 13) % n
+    q = rows[pick].contiguous()
+    del rows
+    D, I = idx.search_device(q, k)
+    info = idx.last_launch()
+    assert info["scan_kind"] == "hi_tile" and info["certificate"]["rejected"] == 0, info
+    assert torch.equal(I[:, 0], pick)
+    if metric == "L2":
+        assert float(D[:, 0].abs().max()) < 1e-6 and bool((D[:, 1:] >= D[:, :-1]).all())
+    else:
+        assert float((D[:, 0] - 1).abs().max()) < 1e-5 and bool((D[:, 1:] <= D[:, :-1]).all())
+    assert int(I.min()) >= 0 and int(I.max()) < n
+    srt = I.sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())                      # distinct ids per query
+    D2, I2 = idx.search_device(q, k)
+    assert torch.equal(I2, I) and torch.equal(D2, D)
