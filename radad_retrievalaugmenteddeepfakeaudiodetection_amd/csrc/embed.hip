@@ -295,6 +295,7 @@ struct ProjPoolParams {
     unsigned short* out_bf16;   // same, emitted as bfloat16 (round to nearest even) instead of `out` when non-null
     float* frames_out;          // optional [S][T][F]: per-frame features (extract_features protocol); no pooling
     const int* n_groups_dev;    // optional: number of valid groups (device-built plan: the grid is an upper bound)
+    int debug;                  // timing experiments only (-DRADAD_DEBUG_HOOKS, RADAD_DEBUG_LOGMEL): 8 = no log-mel loads, 16 = no MFMA tiles
 };
 
 __device__ __forceinline__ unsigned short f32_to_bf16_rne(float v) {      // plain cast: v_cvt_pk_bf16_f32, NaN stays NaN
@@ -329,6 +330,17 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
 
     int nbins = 0;
     for (int l = 0; l < p.n_levels; ++l) nbins += p.levels[l];
+    // frame range [lo, hi) of every pooling bin (pooling.py:78-83), once per workgroup: computed per tile they were two 64-bit
+    // divisions per bin in front of 15 MFMAs
+    __shared__ int s_lo[MAX_BINS_TOTAL], s_hi[MAX_BINS_TOTAL];
+    if (tid < nbins) {
+        int b0 = 0, l = 0;
+        while (tid >= b0 + p.levels[l]) { b0 += p.levels[l]; ++l; }
+        const int lv = p.levels[l], i = tid - b0;
+        s_lo[tid] = (int)(((int64_t)i * p.T) / lv);
+        s_hi[tid] = (int)(((int64_t)(i + 1) * p.T + lv - 1) / lv);
+    }
+    __syncthreads();
 
     // W fragments: lane holds W[16 st + 8 lh + j][feat] (hi and lo), st = 0..4 (K = 80)
     f16x8 wh[5], wl[5];
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
                 const int fr = i / (N_MELS / 4), c4 = i % (N_MELS / 4);
                 f32x4 v = {-10.f, -10.f, -10.f, -10.f};       // log10(1e-10): a frame of pure zero padding
                 const int tt = f0 + fr;
-                if (fr < fcount && tt < p.nf)
+                if (fr < fcount && tt < p.nf && !RADAD_DBG(p.debug, 8))
                     v = *reinterpret_cast<const f32x4*>(p.logmel + ((int64_t)s * p.nf + tt) * N_MELS + c4 * 4);
                 f16x4 vh, vl;
 #pragma unroll
@@ -375,7 +387,7 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
                 *reinterpret_cast<f16x4*>(slm_l + fr * PP_LDH + c4 * 4) = vl;
             }
             __syncthreads();
-            const int ntile = (fcount + 31) / 32;
+            const int ntile = RADAD_DBG(p.debug, 16) ? 0 : (fcount + 31) / 32;
             for (int tile = 0; tile < ntile; ++tile) {
                 f32x16 acc;
 #pragma unroll
@@ -402,12 +414,9 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
                     }
                 } else {
                     const int tlast = min(tfirst + 32, p.T);   // exclusive
-                    int b = 0;
-                    for (int l = 0; l < p.n_levels; ++l) {
-                        const int lv = p.levels[l];
-                        for (int i = 0; i < lv; ++i, ++b) {
-                            const int lo = (int)(((int64_t)i * p.T) / lv);
-                            const int hi = (int)(((int64_t)(i + 1) * p.T + lv - 1) / lv);
+                    for (int b = 0; b < nbins; ++b) {
+                        {
+                            const int lo = s_lo[b], hi = s_hi[b];
                             if (hi <= tfirst || lo >= tlast) continue;        // wave-uniform
                             float v = p.pool_mode == RADAD_POOL_MAX ? -INFINITY : 0.f;
                             if (lo <= tfirst && tfirst + 32 <= hi) {       // whole tile inside the bin (wave-uniform)
@@ -441,18 +450,10 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
         if (!FRAMES_OUT) {
             // segment vector -> running clip sum (each wave only touches its own 32 columns)
             if (lh == 0 && active) {
-                int b = 0;
-                for (int l = 0; l < p.n_levels; ++l) {
-                    const int lv = p.levels[l];
-                    for (int i = 0; i < lv; ++i, ++b) {
-                        float v = spool[b * PP_FEATS + fl];
-                        if (p.pool_mode == RADAD_POOL_AVG) {
-                            const int lo = (int)(((int64_t)i * p.T) / lv);
-                            const int hi = (int)(((int64_t)(i + 1) * p.T + lv - 1) / lv);
-                            v = v / (float)(hi - lo);
-                        }
-                        sclip[b * PP_FEATS + fl] += v;
-                    }
+                for (int b = 0; b < nbins; ++b) {
+                    float v = spool[b * PP_FEATS + fl];
+                    if (p.pool_mode == RADAD_POOL_AVG) v = v / (float)(s_hi[b] - s_lo[b]);
+                    sclip[b * PP_FEATS + fl] += v;
                 }
             }
         }
@@ -759,6 +760,10 @@ static void fill_projpool(radad_embed_t h, ProjPoolParams& p) {
     p.nf = h->nf; p.T = h->T; p.F = h->cfg.feat_dim; p.wfrag_h = h->wfrag_h; p.wscale = h->wscale; p.bias = h->bias; p.n_levels = h->cfg.n_levels;
     for (int i = 0; i < RADAD_MAX_LEVELS; ++i) p.levels[i] = i < h->cfg.n_levels ? h->cfg.levels[i] : 0;
     p.pool_mode = h->cfg.pool_mode; p.out = nullptr; p.out_bf16 = nullptr; p.frames_out = nullptr; p.n_groups_dev = nullptr;
+    p.debug = 0;
+#ifdef RADAD_DEBUG_HOOKS
+    { const char* dbg = getenv("RADAD_DEBUG_LOGMEL"); p.debug = dbg ? atoi(dbg) : 0; }
+#endif
 }
 
 extern "C" {
