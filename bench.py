@@ -40,11 +40,37 @@ AUDIO_SEED, DB_SEED, NOISE_SEED = 1234, 4321, 99
 PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
 PEAK_MFMA_F16_TFLOPS = 2500.0     # same guide: BF16/F16 MFMA ~2.5 PF dense (at 2.4 GHz; MFMA-dense loops hold 1.5-1.95 GHz)
 PEAK_HBM_GBPS = 8000.0
-# HBM-side bytes of ONE scan launch of the default 1-GPU workload, from the PMC passes of the same command
-# (profiles/r2_d_pmc_summary.txt, tools/profile_r1.sh): FETCH_SIZE (KB) x 2 (gfx950 reports half of a 16-B/lane stream,
-# MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KB).  Infinity-Cache hits are counted in FETCH_SIZE, so this is an upper bound on
-# DRAM traffic; it is only meaningful for that exact workload.  k_knn_hi reads the f16 hi plane (1.024 GB) once: 1.04x.
-SCAN_TRAFFIC_BYTES = {"k_knn_hi": 509305.0 * 1024 * 2 + 18944.1 * 1024, "k_knn_f32_reg": 4.18399e6 * 1024 * 2 + 8195.59 * 1024}
+
+
+def scan_traffic_from_profiles(section):
+    """HBM-side bytes of ONE scan launch of the default 1-GPU workload: FETCH_SIZE (KB) x 2 (gfx950 reports half of a 16-B/lane
+    stream, MI355X_MICROARCH.md "HBM") + WRITE_SIZE (KB), read from the newest profiles/*_pmc_summary.txt (the PMC passes of this
+    same command, tools/profile_r1.sh; RADAD_PMC_SUMMARY names another file).  PMC counters cannot be collected inside the run
+    that prints the line (separate rocprofv3 passes), so the figure is only as fresh as that file: its name travels with the
+    number in `traffic_source`.  Infinity-Cache hits are counted in FETCH_SIZE: an upper bound on DRAM traffic."""
+    import glob
+    import re
+    cand = [os.environ["RADAD_PMC_SUMMARY"]] if os.environ.get("RADAD_PMC_SUMMARY") else \
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
+    for path in reversed(cand):
+        try:
+            text = open(path).read()
+        except OSError:
+            continue
+        vals, cur = {}, None
+        for line in text.splitlines():
+            if line and not line[0].isspace() and not line.startswith("#"):
+                cur = line.strip()
+            elif cur == section:
+                m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+mean\s+([0-9.eE+-]+)", line)
+                if m:
+                    vals[m.group(1)] = float(m.group(2))
+        if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+            return vals["FETCH_SIZE"] * 1024 * 2 + vals["WRITE_SIZE"] * 1024, {
+                "file": os.path.relpath(path, ROOT), "kernel_section": section, "fetch_size_kb": vals["FETCH_SIZE"],
+                "write_size_kb": vals["WRITE_SIZE"], "formula": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024",
+                "measured_in_this_run": False}
+    return None, None
 
 
 def main():
@@ -59,8 +85,14 @@ def main():
     ap.add_argument("--sustain", type=float, default=5.0, help="seconds of the same step looped after the timed steps (0 = skip)")
     ap.add_argument("--pcie", type=float, default=2.0, help="seconds of the step looped with every batch's audio crossing PCIe "
                     "(pinned host -> device, double-buffered on a copy stream, overlapped with the previous step); 0 = skip")
+    ap.add_argument("--unstructured", type=int, default=10, help="searches of 1024 random (unstructured) queries timed after the "
+                    "headline steps for the `scan_unstructured_ms` key (0 = skip)")
     ap.add_argument("--mode", choices=["step", "predict"], default="step")
     ap.add_argument("--predict-queries", type=int, default=1)
+    ap.add_argument("--dim", type=int, default=DIM, help="--mode predict only: embedding dimension of the store (the reference's own "
+                    "stores are 5376- or 3584-dimensional: 7 pyramid bins x 768 / 512 features); != 512 uses synthetic queries")
+    ap.add_argument("--metric", choices=["cosine", "l2"], default="cosine", help="--mode predict only (the reference's default index is L2)")
+    ap.add_argument("--k", type=int, default=TOP_K, help="--mode predict only (the reference searches K + 10 = 15)")
     ap.add_argument("--workload", choices=["fixed", "ragged"], default="fixed",
                     help="fixed = 4 s clips (the headline); ragged = BASELINE config 3: release_in_the_wild-shaped variable-length "
                          "clips (log-normal, mean ~4.3 s, clipped to [0.5, 20] s) cut by the segmenter rule")
@@ -102,12 +134,53 @@ def main():
     from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import ShardedSearch, shard_bounds
     lib = _lib.load()
 
+    if args.mode == "predict" and (args.dim != DIM or args.metric != "cosine" or args.k != TOP_K):
+        # ---- the online search at the reference's own shape (pipeline.py:1038-1054: ONE query, D = 5376 / 3584, k = 15, L2 by
+        # default; config.py:48-56): synthetic embeddings (there is no D-dimensional encoder here), one planted neighbour per query
+        assert world == 1, "--mode predict is a one-GPU measurement"
+        dim, n_rows, k = args.dim, args.db_rows, args.k
+        rows = torch.empty((n_rows, dim), device=dev, dtype=torch.float32)
+        _lib.check(lib.radad_synth_rows(rows.data_ptr(), 0, n_rows, dim, DB_SEED, local_rank, _lib.stream_ptr(dev)))
+        nqp = max(1, min(16, args.predict_queries))
+        qp = torch.empty((nqp, dim), device=dev, dtype=torch.float32)
+        _lib.check(lib.radad_synth_rows(qp.data_ptr(), 0, nqp, dim, 977, local_rank, _lib.stream_ptr(dev)))
+        planted = (torch.arange(nqp, device=dev) * 977 + 17) % n_rows
+        rows[planted] = qp + 0.05 * rows[:nqp]
+        index = R.HipFlatIndex(dim, _lib.METRIC_L2 if args.metric == "l2" else _lib.METRIC_COSINE, local_rank,
+                               store_f16=(args.store_dtype == "f16"))
+        index.add_device(rows)
+        for _ in range(args.warmup):
+            index.search_device(qp, k)
+        torch.cuda.synchronize()
+        index.profile(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            D, I = index.search_device(qp, k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        scan = float(np.mean(index.profile_read()))
+        launch = index.last_launch()
+        esz = 2.0 if (args.store_dtype == "f16" or launch["scan_kind"] in ("hi_smallq", "hi_tile")) else 4.0
+        byts = esz * n_rows * dim + 4.0 * nqp * dim + 12.0 * nqp * k
+        out = {"metric": f"searches/sec (retrieve, online predict path) @{n_rows}x{dim} DB", "value": round(args.steps / dt, 1),
+               "unit": "searches/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{nqp} query(ies) per search, {args.metric} top-{k}, {n_rows} x {dim} {args.store_dtype} store",
+                          "queries_per_search": nqp, "db_rows": n_rows, "dim": dim, "k": k},
+               "roofline": {"kernel": launch["scan_kind"], "bound": "hbm", "achieved": round(byts / (scan * 1e-3) / 1e9, 1),
+                            "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(byts / (scan * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                            "traffic": None, "kernel_ms": round(scan, 4), "algorithmic_bytes_per_launch": byts, "launch": launch},
+               "planted_neighbours_found": bool((I[:, 0] == planted).all().item())}
+        print(json.dumps(out), flush=True)
+        return
+
     cfg = R.Config()
     cfg.update(device=dev, tpp_levels=[1], tpp_pooling_type="max", feature_dim=DIM, vector_db_index_type="IP",
                use_float16=(args.store_dtype == "f16"))
     fe = R.MelProjectionFeatureExtractor(cfg)
     B = args.clips
     n_total = args.db_rows
+    f16_store = args.store_dtype == "f16"
     lo, hi = shard_bounds(n_total, world, rank)
     emb_dtype = torch.bfloat16 if args.embed_dtype == "bf16" else torch.float32
 
@@ -261,6 +334,30 @@ def main():
         sustained = {"seconds": round(el, 2), "steps": n_s, "value": round(world * B * n_s / el, 1), "unit": "clips/s",
                      "ms_per_step": round(1e3 * el / n_s, 4), "scan_ms": round(float(np.mean(k2)), 4),
                      "k_logmel_ms": round(float(np.mean(l2_)), 4), "k_proj_pool_ms": round(float(np.mean(p2_)), 4)}
+    # ---- the same scan on UNSTRUCTURED queries (random directions against the same store: no planted rows near them, so the
+    # sample-based admission floor is low and the epilogue's push / drain path works hardest -- what a store of unrelated
+    # embeddings looks like to the filter), cosine on the benchmark's store and L2 (the reference's default metric) on a copy
+    scan_unstructured = None
+    if world == 1 and args.unstructured > 0:
+        qu = torch.empty((B, DIM), device=dev, dtype=torch.float32)
+        _lib.check(lib.radad_synth_rows(qu.data_ptr(), 0, B, DIM, 977, local_rank, _lib.stream_ptr(dev)))
+        scan_unstructured = {}
+        l2_index = R.HipFlatIndex(DIM, _lib.METRIC_L2, local_rank, store_f16=f16_store)
+        l2_index.add_device(rows)
+        for name, index in (("cosine", vdb.index), ("l2", l2_index)):
+            index.profile(False)
+            for _ in range(3):
+                index.search_device(qu, TOP_K)
+            index.profile(True)
+            for _ in range(args.unstructured):
+                index.search_device(qu, TOP_K)
+            ms_u = index.profile_read()
+            la = index.last_launch()
+            scan_unstructured[name] = {"scan_ms": round(float(np.mean(ms_u)), 4), "scan_kind": la["scan_kind"],
+                                       "rejected": la["certificate"]["rejected"],
+                                       "candidates_per_query": round(la["certificate"]["candidates_rescored"] / B, 1)}
+            index.profile(False)
+        del l2_index, qu
     fe.profile(False)
     vdb.index.profile(False)
 
@@ -341,9 +438,9 @@ def main():
         peak = PEAK_MFMA_F16_TFLOPS if f16 else PEAK_MFMA_F32_TFLOPS
         scan_desc = "fp32 MFMA scan; float64 re-rank from the stored rows"
     dtype = ("f32" if args.embed_dtype == "f32" else "bf16 embeddings") + (" / f16 store" if f16 else "") + " (" + scan_desc + ")"
-    traffic = None
-    if world == 1 and B == CLIPS_PER_GPU and n_total == DB_ROWS and not f16 and args.workload == "fixed":
-        traffic = SCAN_TRAFFIC_BYTES["k_knn_hi" if wide else "k_knn_f32_reg"]
+    traffic, traffic_source = None, None
+    if world == 1 and B == CLIPS_PER_GPU and n_total == DB_ROWS and not f16 and args.workload == "fixed" and wide:
+        traffic, traffic_source = scan_traffic_from_profiles("k_knn_hi")
     lm_avg = float(np.mean(lm_ms)) if lm_ms else float("nan")
     pp_avg = float(np.mean(pp_ms)) if pp_ms else float("nan")
     # per-segment algorithmic work of the two embedding kernels: unfolded 400-tap real DFT of 201 bins
@@ -375,7 +472,7 @@ def main():
                    "planted_neighbours_found": planted_ok},
         "roofline": {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 2),
                      "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": traffic,
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_ms": round(knn_avg, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
                      "kernel_operand_bytes_per_launch": (2.0 * (hi - lo) * DIM + 2.0 * Q * DIM + 8.0 * Q * launch["db_splits"] * 16) if wide else alg_bytes,
                      "hbm_GBps_algorithmic": round(alg_bytes / (knn_avg * 1e-3) / 1e9, 1),
@@ -384,6 +481,9 @@ def main():
         "kernels": {"k_logmel_h": kroof(lm_avg, lm_flops, lm_bytes), "k_proj_pool": kroof(pp_avg, pp_flops, pp_bytes)},
         "kernels_ms": {"k_logmel": round(lm_avg, 4), "k_proj_pool": round(pp_avg, 4), "scan": round(knn_avg, 4)},
     }
+    if scan_unstructured:
+        out["scan_unstructured_ms"] = {k_: v_["scan_ms"] for k_, v_ in scan_unstructured.items()}
+        out["scan_unstructured"] = scan_unstructured
     if sustained:
         out["sustained"] = sustained
     if pcie:

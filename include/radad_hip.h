@@ -253,6 +253,14 @@ int radad_embed_forward_ex(radad_embed_t h, const float* wave_dev, const int64_t
  * segments for buffer and grid sizes. */
 int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_dev, int64_t n_clips,
                             int64_t n_samples_total, void* out_dev, int out_dtype, void* stream);
+/* The device-resident offsets cannot be validated by the host without a synchronisation (the host path of
+ * radad_embed_forward rejects bad offsets up front, as segmenter.py:18-19 raises on bad input).  The plan kernel therefore
+ * REPAIRS them -- every clip is clamped into [0, n_samples_total], a clip that ends before it starts becomes empty, the
+ * segment count is capped -- so no kernel reads outside the wave buffer, and records what it repaired.  This call waits for the
+ * most recent radad_embed_forward_dev batch and returns (once) those flags: 0 = offsets were fine; bit 0 an offset outside
+ * [0, n_samples_total]; bit 1 non-monotone offsets; bit 2 more segments than n_samples_total / hop + n_clips.  A non-zero
+ * value means the embeddings of that batch are NOT those of the intended clips. */
+int radad_embed_plan_flags(radad_embed_t h, int* flags_out);
 
 /* same HIP-event timing for the two embedding kernels (k_logmel, k_proj_pool) of radad_embed_forward */
 int radad_embed_profile(radad_embed_t h, int enable);

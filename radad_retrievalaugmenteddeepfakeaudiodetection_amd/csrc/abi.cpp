@@ -1,7 +1,10 @@
 // abi.cpp -- error text, version and device probes of libradad_hip.so.
 #include "common.h"
 
+#include <mutex>
+#include <set>
 #include <string>
+#include <stdlib.h>
 
 static thread_local std::string g_err;
 
@@ -12,6 +15,17 @@ void radad_set_error(const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_err = buf;
+}
+
+const char* radad_env_override(const char* name, const char* effect) {
+    const char* e = getenv(name);
+    if (e) {
+        static std::mutex mu;
+        static std::set<std::string> said;
+        std::lock_guard<std::mutex> lk(mu);
+        if (said.insert(name).second) fprintf(stderr, "[libradad_hip] %s=%s is set: %s\n", name, e, effect);
+    }
+    return e;
 }
 
 extern "C" {

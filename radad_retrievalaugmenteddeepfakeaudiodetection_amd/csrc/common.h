@@ -27,6 +27,11 @@ void radad_set_error(const char* fmt, ...);
         }                                                                                             \
     } while (0)
 
+// Environment overrides of the default kernel choice (RADAD_KNN_HI, RADAD_KNN_SMALLQ_HI, RADAD_WIDE_MIN_Q, RADAD_LOGMEL_F32) select
+// CORRECT but slower paths (8x on the scan); a stray variable must not do that silently: the first read of each one that is set
+// is announced once per process on stderr.  Returns the variable's value (nullptr when unset).
+const char* radad_env_override(const char* name, const char* effect);
+
 // Timing-experiment switches inside kernels (skip a phase and measure the rest): compiled out unless the library is built
 // with -DRADAD_DEBUG_HOOKS, so that no environment variable can make the shipped kernels skip work.
 #ifdef RADAD_DEBUG_HOOKS

@@ -537,20 +537,32 @@ __global__ __launch_bounds__(256) void k_group_mean(const float* __restrict__ in
 // window is dropped).  One workgroup: chunks of 1024 clips, an exclusive scan of n_seg with a running carry, then every
 // thread writes its own clip's segments.  Outputs: clip_seg [B+1], seg_start [S], seg_valid [S], n_seg_out[0] = S.
 // Nothing here needs the host: a batch with fresh offsets costs one tiny launch, no synchronisation.
+// The offsets are DEVICE data nobody has looked at: every clip is clamped into [0, total) (total = samples in the wave buffer, or
+// -1: unknown, only negative lengths are repaired) and the segment count to seg_cap, so that whatever the tensor holds the kernels
+// behind this one read inside the wave buffer and inside their own scratch.  n_seg_out[1] reports what had to be repaired:
+// bit 0 an offset outside [0, total], bit 1 a clip ending before it starts, bit 2 more segments than seg_cap.
 __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__ off, int64_t n_clips, int L, int hop,
-                                                     int64_t seg_cap, int64_t* __restrict__ clip_seg, int64_t* __restrict__ seg_start,
-                                                     int* __restrict__ seg_valid, int* __restrict__ n_seg_out) {
+                                                     int64_t seg_cap, int64_t total, int64_t* __restrict__ clip_seg,
+                                                     int64_t* __restrict__ seg_start, int* __restrict__ seg_valid, int* __restrict__ n_seg_out) {
     __shared__ long long s_wave[16];
     __shared__ long long s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_carry = 0;
     __syncthreads();
+    int bad = 0;
     for (int64_t b0 = 0; b0 < n_clips; b0 += 1024) {
         const int64_t b = b0 + tid;
-        long long n = 0, ns = 0;
+        long long n = 0, ns = 0, beg = 0;
         if (b < n_clips) {
-            n = off[b + 1] - off[b];
-            if (n < 0) n = 0;
+            long long end = off[b + 1];
+            beg = off[b];
+            if (total >= 0) {
+                const long long cb = beg < 0 ? 0 : (beg > total ? total : beg), ce = end < 0 ? 0 : (end > total ? total : end);
+                if (cb != beg || ce != end) bad |= 1;
+                beg = cb; end = ce;
+            }
+            n = end - beg;
+            if (n < 0) { n = 0; bad |= 2; }
             const long long d = n - L;
             long long q = d / hop;
             if ((d % hop != 0) && (d < 0)) --q;          // floor division
@@ -568,10 +580,10 @@ __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__
         for (int w = 0; w < wave; ++w) base += s_wave[w];
         const long long first = base + inc - ns;         // exclusive prefix of this clip
         if (b < n_clips) {
-            clip_seg[b] = first;
+            clip_seg[b] = first < seg_cap ? first : seg_cap;
             for (long long i = 0; i < ns; ++i) {
                 if (first + i < seg_cap) {
-                    seg_start[first + i] = off[b] + i * hop;
+                    seg_start[first + i] = beg + i * hop;
                     const long long v = n - i * hop;
                     seg_valid[first + i] = (int)(v < 0 ? 0 : (v > L ? L : v));
                 }
@@ -581,9 +593,11 @@ __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__
         if (tid == 1023) s_carry = base + inc;
         __syncthreads();
     }
+    bad = __syncthreads_or(bad);
     if (tid == 0) {
-        clip_seg[n_clips] = s_carry;
+        clip_seg[n_clips] = s_carry < seg_cap ? s_carry : seg_cap;
         n_seg_out[0] = (int)(s_carry < seg_cap ? s_carry : seg_cap);
+        n_seg_out[1] = bad | (s_carry > seg_cap ? 4 : 0);
     }
 }
 
@@ -632,6 +646,9 @@ struct radad_embed_s {
     size_t pin_cap[2] = {0, 0};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     int pin_next = 0;
+    int* plan_flags_host = nullptr;      // pinned: what k_build_plan repaired in the most recent device-offset batch
+    hipEvent_t plan_flags_ev = nullptr;
+    bool plan_flags_pending = false;
     EventRing prof_logmel, prof_pool;
     std::mutex mu;
 };
@@ -653,14 +670,14 @@ static int upload(DevBuf& b, const void* host, size_t bytes, hipStream_t st) {
 }
 
 // Launch k_build_plan over device-resident offsets.  seg_cap bounds the number of segments (buffers and grids).
-static int plan_on_device(radad_embed_t h, const int64_t* clip_off_dev, int64_t n_clips, int64_t seg_cap, hipStream_t st) {
+static int plan_on_device(radad_embed_t h, const int64_t* clip_off_dev, int64_t n_clips, int64_t seg_cap, int64_t total, hipStream_t st) {
     int rc;
     if ((rc = h->seg_start.ensure((size_t)seg_cap * sizeof(int64_t)))) return rc;
     if ((rc = h->seg_valid.ensure((size_t)seg_cap * sizeof(int32_t)))) return rc;
     if ((rc = h->clip_seg.ensure((size_t)(n_clips + 1) * sizeof(int64_t)))) return rc;
-    if ((rc = h->n_seg_dev.ensure(sizeof(int)))) return rc;
+    if ((rc = h->n_seg_dev.ensure(2 * sizeof(int)))) return rc;
     hipLaunchKernelGGL(k_build_plan, dim3(1), dim3(1024), 0, st, clip_off_dev, n_clips, h->cfg.segment_length, h->cfg.hop_length,
-                       seg_cap, (int64_t*)h->clip_seg.p, (int64_t*)h->seg_start.p, (int*)h->seg_valid.p, (int*)h->n_seg_dev.p);
+                       seg_cap, total, (int64_t*)h->clip_seg.p, (int64_t*)h->seg_start.p, (int*)h->seg_valid.p, (int*)h->n_seg_dev.p);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
 }
@@ -700,7 +717,7 @@ static int build_plan(radad_embed_t h, const int64_t* clip_offsets, int64_t n_cl
     RADAD_HIP_CHECK(hipMemcpyAsync(h->clip_off.p, h->pin[slot], need, hipMemcpyHostToDevice, st));
     RADAD_HIP_CHECK(hipEventRecord(h->pin_ev[slot], st));
     h->pin_next ^= 1;
-    if ((rc = plan_on_device(h, (const int64_t*)h->clip_off.p, n_clips, std::max<int64_t>(n_seg, 1), st))) return rc;
+    if ((rc = plan_on_device(h, (const int64_t*)h->clip_off.p, n_clips, std::max<int64_t>(n_seg, 1), -1, st))) return rc;
     h->plan_uniform = uniform;
     h->plan_on_device = false;
     h->plan_key.assign(clip_offsets, clip_offsets + n_clips + 1);
@@ -912,7 +929,7 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
         if (hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { radad_set_error("H2D copy failed"); return RADAD_EHIP; }
         return RADAD_OK;
     };
-    { const char* e = getenv("RADAD_LOGMEL_F32"); h->logmel_f32 = (e && atoi(e) != 0) ? 1 : 0; }
+    { const char* e = radad_env_override("RADAD_LOGMEL_F32", "non-zero selects the fp32-MFMA log-mel kernel (k_logmel, ~2x slower) for extractors created from now on"); h->logmel_f32 = (e && atoi(e) != 0) ? 1 : 0; }
     int rc = put(&h->basis, basis.data(), basis.size() * sizeof(float));
     if (!rc) rc = put((float**)&h->basis_h, basis_h.data(), basis_h.size() * sizeof(_Float16));
     if (!rc) rc = put(&h->fbfrag, fbfrag.data(), fbfrag.size() * sizeof(float));
@@ -957,6 +974,8 @@ int radad_embed_destroy(radad_embed_t h) {
             if (h->pin[i]) (void)hipHostFree(h->pin[i]);
             if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
         }
+        if (h->plan_flags_host) (void)hipHostFree(h->plan_flags_host);
+        if (h->plan_flags_ev) (void)hipEventDestroy(h->plan_flags_ev);
         h->misc.release();
         h->prof_logmel.destroy();
         h->prof_pool.destroy();
@@ -1037,12 +1056,33 @@ int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_
     // bound, the kernels read the true count from the device
     const int64_t seg_cap = n_samples_total / h->cfg.hop_length + n_clips;
     RADAD_REQUIRE(seg_cap < (1ll << 31), "radad_embed_forward_dev: too many segments in one batch");
-    int rc = plan_on_device(h, clip_offsets_dev, n_clips, seg_cap, st);
+    int rc = plan_on_device(h, clip_offsets_dev, n_clips, seg_cap, n_samples_total, st);
     if (rc) return rc;
     h->plan_key.clear();
     h->plan_on_device = true;
     h->plan_nseg = seg_cap;
-    return embed_run(h, wave_dev, n_clips, seg_cap, false, out_dev, out_dtype, (const int*)h->n_seg_dev.p, st);
+    if ((rc = embed_run(h, wave_dev, n_clips, seg_cap, false, out_dev, out_dtype, (const int*)h->n_seg_dev.p, st))) return rc;
+    // what k_build_plan had to repair travels to pinned host memory behind the batch (radad_embed_plan_flags waits for it)
+    if (!h->plan_flags_host) {
+        RADAD_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->plan_flags_host), sizeof(int), hipHostMallocDefault));
+        RADAD_HIP_CHECK(hipEventCreateWithFlags(&h->plan_flags_ev, hipEventDisableTiming));
+    }
+    RADAD_HIP_CHECK(hipMemcpyAsync(h->plan_flags_host, (const int*)h->n_seg_dev.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    RADAD_HIP_CHECK(hipEventRecord(h->plan_flags_ev, st));
+    h->plan_flags_pending = true;
+    return RADAD_OK;
+}
+
+int radad_embed_plan_flags(radad_embed_t h, int* flags_out) {
+    RADAD_REQUIRE(h && flags_out, "radad_embed_plan_flags: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    *flags_out = 0;
+    if (!h->plan_flags_pending) return RADAD_OK;
+    RADAD_HIP_CHECK(hipEventSynchronize(h->plan_flags_ev));
+    *flags_out = *h->plan_flags_host;
+    h->plan_flags_pending = false;           // reported once
+    return RADAD_OK;
 }
 
 int radad_embed_profile(radad_embed_t h, int enable) {

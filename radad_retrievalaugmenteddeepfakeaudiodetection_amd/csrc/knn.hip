@@ -659,7 +659,7 @@ __global__ __launch_bounds__(KNN_THREADS, 2) void k_knn_f32_reg(KnnParams p) {
 constexpr int SQ_THREADS = 256;
 constexpr int SQ_NQ = 16;
 constexpr int SQ_SLOTS = 16;
-constexpr int SQ_MAX_DIM = 2048;
+constexpr size_t SQ_LDS_BUDGET = 160 * 1024;      // the query block [nq][dim + pad] + slot buffers must fit one CU's LDS
 
 struct SmallQParams {
     const float* db; const float* ynorm; const float* q;      // fp32 store only
@@ -674,18 +674,17 @@ template <int KSEL>
 __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_f32_smallq(SmallQParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int qld = p.dim + 4;                                    // padded query row: conflict-free b128 reads
-    float* sQ = reinterpret_cast<float*>(smem);                   // [16][dim + 4]
-    float2* sCand = reinterpret_cast<float2*>(sQ + SQ_NQ * qld);  // [4 waves][16 q][SQ_SLOTS]
+    float* sQ = reinterpret_cast<float*>(smem);                   // [nq][dim + 4]: only the queries there are (the reference's
+                                                                  // predict() search is ONE query of dim 5376 / 3584)
+    float2* sCand = reinterpret_cast<float2*>(sQ + p.nq * qld);   // [4 waves][16 q][SQ_SLOTS]
     int* sCnt = reinterpret_cast<int*>(sCand + 4 * SQ_NQ * 24);         // [4 waves][16]; the slot area is sized for the final
                                                                         // hand-over of 3 x 16 x 32 keys (12 KB) as well
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    for (int i = tid; i < SQ_NQ * (p.dim >> 2); i += SQ_THREADS) {
+    for (int i = tid; i < p.nq * (p.dim >> 2); i += SQ_THREADS) {
         const int qq = i / (p.dim >> 2), c4 = i % (p.dim >> 2);
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (qq < p.nq) v = *reinterpret_cast<const f32x4*>(p.q + (int64_t)qq * p.dim + c4 * 4);
-        *reinterpret_cast<f32x4*>(sQ + qq * qld + c4 * 4) = v;
+        *reinterpret_cast<f32x4*>(sQ + qq * qld + c4 * 4) = *reinterpret_cast<const f32x4*>(p.q + (int64_t)qq * p.dim + c4 * 4);
     }
     if (tid < 4 * SQ_NQ) sCnt[tid] = 0;
     __syncthreads();
@@ -703,7 +702,7 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_f32_smallq(SmallQParams p
     float thr = -INFINITY;               // threshold of query (lane & 15), refreshed from the owner lane
     // K mapping inside a 32-float block: load h (0/1), element j of lane group g is k = 16h + 4g + j, so one load
     // instruction reads 64 CONTIGUOUS bytes of each of its 16 rows and the pair covers the whole 128-byte line.
-    const float* qrow = sQ + r16 * qld + 4 * g;
+    const float* qrow = sQ + min(r16, p.nq - 1) * qld + 4 * g;     // columns >= nq repeat the last query (never admitted below)
     const int nkb = p.dim >> 5;
 
     for (int64_t row0 = w_begin; row0 < w_end; row0 += 16) {
@@ -807,17 +806,15 @@ template <int KSEL>
 __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int qld = p.dim + 8;                                    // padded query row (halfs): 16-byte chunks of the 16 rows fall in distinct banks
-    _Float16* sQ = reinterpret_cast<_Float16*>(smem);             // [16][dim + 8]
-    float2* sCand = reinterpret_cast<float2*>(sQ + SQ_NQ * qld);  // [4 waves][16 q][SQ_SLOTS]
+    _Float16* sQ = reinterpret_cast<_Float16*>(smem);             // [nq][dim + 8]
+    float2* sCand = reinterpret_cast<float2*>(sQ + p.nq * qld);   // [4 waves][16 q][SQ_SLOTS]
     int* sCnt = reinterpret_cast<int*>(sCand + 4 * SQ_NQ * 24);   // [4 waves][16]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    for (int i = tid; i < SQ_NQ * (p.dim >> 3); i += SQ_THREADS) {
+    for (int i = tid; i < p.nq * (p.dim >> 3); i += SQ_THREADS) {
         const int qq = i / (p.dim >> 3), c8 = i % (p.dim >> 3);
-        f16x8 v = {};
-        if (qq < p.nq) v = *reinterpret_cast<const f16x8*>(p.q + (int64_t)qq * p.dim + c8 * 8);
-        *reinterpret_cast<f16x8*>(sQ + qq * qld + c8 * 8) = v;
+        *reinterpret_cast<f16x8*>(sQ + qq * qld + c8 * 8) = *reinterpret_cast<const f16x8*>(p.q + (int64_t)qq * p.dim + c8 * 8);
     }
     if (tid < 4 * SQ_NQ) sCnt[tid] = 0;
     __syncthreads();
@@ -836,7 +833,7 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams 
     const float qs = r16 < p.nq ? p.qscale[r16] : 0.f;
     // lane (r16, g) holds elements 32 kb + 8 g .. + 7 of row r16 (A) and of query r16 (B): one load instruction reads 64
     // contiguous bytes of each of its 16 rows, two consecutive ones a whole 128-byte line
-    const _Float16* qrow = sQ + r16 * qld + 8 * g;
+    const _Float16* qrow = sQ + min(r16, p.nq - 1) * qld + 8 * g;   // columns >= nq repeat the last query (never admitted below)
     const int nkb = p.dim >> 5;
 
     for (int64_t row0 = w_begin; row0 < w_end; row0 += 16) {
@@ -1359,7 +1356,11 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     const int nrank = RADAD_DBG(p.debug, 512) ? 0 : nsel;
     for (int c = tid; c < nrank; c += RF_THREADS) {
         c_gid[c] = p.id_map ? p.id_map[c_id[c]] : (int64_t)c_id[c];
-        if (p.l2) c_key[c] = -c_key[c];
+        double kc = p.l2 ? -c_key[c] : c_key[c];
+        // a NaN key (non-finite query or row) compares false with everything: several candidates would take the same rank and
+        // leave output slots unwritten.  It ranks last instead, among its kind by id: the order stays total.
+        if (kc != kc) kc = -(double)INFINITY;
+        c_key[c] = kc;
     }
     __syncthreads();
     {
@@ -1761,11 +1762,16 @@ struct radad_knn_s {
     int64_t stat_rows = 0;
     // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
     // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
-    int* host_count = nullptr;   // pinned [8]: rejected queries, sum of candidates, rejections by reason x 4
+    // The counters of search i land in slot i % 2 and are CONSUMED by search i + 2 behind a wait on that slot's event (long due by
+    // then: the host is never more than two searches ahead of the device), so which kernels a search sequence runs does not depend
+    // on host / device timing -- the first version polled the previous search's event with hipEventQuery and could take the f16
+    // scan in one run and the fp32 scan in another.
+    int* host_count = nullptr;   // pinned [2][8]: rejected queries, sum of candidates, rejections by reason x 4
     int* host_count_dev = nullptr;   // the same memory as the device sees it
-    hipEvent_t ev_count = nullptr, ev_done = nullptr;
-    bool count_pending = false, done_recorded = false;
-    int64_t count_nq = 0;        // batch size of the search host_count belongs to
+    hipEvent_t ev_count[2] = {nullptr, nullptr}, ev_done = nullptr;
+    bool count_pending[2] = {false, false}, done_recorded = false;
+    int64_t count_nq[2] = {0, 0};    // batch size of the search a slot belongs to
+    uint64_t search_seq = 0;     // certified searches so far
     int hi_skip = 0;             // searches left on the fp32 kernels after the certified scan rejected too many queries
     size_t esize() const { return f16 ? 2 : 4; }
     size_t row_bytes() const { return (size_t)dim * esize(); }
@@ -1908,17 +1914,18 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
     if (!h) { radad_set_error("out of host memory"); return RADAD_ENOMEM; }
     h->dim = dim; h->metric = metric; h->device = device; h->id_base = id_base; h->f16 = store_dtype == RADAD_STORE_F16;
     // RADAD_KNN_HI=0 keeps every search on the fp32 kernels (bench.py --scan f32); read once, at creation
-    { const char* e = getenv("RADAD_KNN_HI"); h->hi_off = (e && atoi(e) == 0) ? 1 : 0; }
+    { const char* e = radad_env_override("RADAD_KNN_HI", "0 keeps every search of stores created from now on off the certified f16 scan (fp32 kernels: ~8x slower scans)"); h->hi_off = (e && atoi(e) == 0) ? 1 : 0; }
     {
         DeviceGuard g(device);
-        if (hipHostMalloc(reinterpret_cast<void**>(&h->host_count), 8 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_count, hipEventDisableTiming) != hipSuccess ||
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->host_count), 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_count[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_count[1], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess) {
             radad_set_error("radad_knn_create: pinned counter / events could not be created");
             radad_knn_destroy(h);
             return RADAD_EHIP;
         }
-        memset(h->host_count, 0, 8 * sizeof(int));
+        memset(h->host_count, 0, 16 * sizeof(int));
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h->host_count_dev), h->host_count, 0) != hipSuccess) {
             radad_set_error("radad_knn_create: pinned counter is not device-visible");
             radad_knn_destroy(h);
@@ -1940,7 +1947,7 @@ int radad_knn_destroy(radad_knn_t h) {
         if (h->rscale) (void)hipFree(h->rscale);
         if (h->stat) (void)hipFree(h->stat);
         if (h->host_count) (void)hipHostFree(h->host_count);
-        if (h->ev_count) (void)hipEventDestroy(h->ev_count);
+        for (int i = 0; i < 2; ++i) if (h->ev_count[i]) (void)hipEventDestroy(h->ev_count[i]);
         if (h->ev_done) (void)hipEventDestroy(h->ev_done);
         h->prof.destroy();
     }
@@ -2080,27 +2087,38 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     // the device work by this event)
     if (h->done_recorded) RADAD_HIP_CHECK(hipStreamWaitEvent(st, h->ev_done, 0));
 
-    // how the previous search's certificate fared (its count has long landed; never wait for it here)
-    if (h->count_pending && hipEventQuery(h->ev_count) == hipSuccess) {
-        h->count_pending = false;
-        if (h->hi_skip == 0 && h->count_nq >= 64 && (int64_t)*h->host_count * 4 > h->count_nq) h->hi_skip = 8;
+    const bool cert = k <= KNN_CERT_MAX_K;      // beyond: legacy k + margin candidates, no certificate
+    // how the certificate of the search TWO back fared (fixed lag: see the handle); this search takes over its slot
+    const int cslot = (int)(h->search_seq & 1);
+    if (cert && h->count_pending[cslot]) {
+        RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count[cslot]));
+        h->count_pending[cslot] = false;
+        if (h->hi_skip == 0 && h->count_nq[cslot] >= 64 && (int64_t)h->host_count[8 * cslot] * 4 > h->count_nq[cslot]) h->hi_skip = 8;
     }
 #ifdef RADAD_DEBUG_HOOKS
     if (getenv("RADAD_DEBUG_KNN")) h->hi_skip = 0;     // timing ablations (wrong results, every query rejected): stay on the kernel under test
 #endif
-    const bool cert = k <= KNN_CERT_MAX_K;      // beyond: legacy k + margin candidates, no certificate
     const int l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0;
 
     // ---- choice of the scan -------------------------------------------------------------------------------------
     int n_qtiles, n_splits;
     int64_t chunk_rows;
     knn_geometry(std::max<int64_t>(h->ntotal, 1), nq, &n_qtiles, &n_splits, &chunk_rows);
-    static const int wide_min_q = [] { const char* e = getenv("RADAD_WIDE_MIN_Q"); return e ? atoi(e) : SQ_NQ + 1; }();
-    bool use_hi = false;
+    static const int wide_min_q = [] { const char* e = radad_env_override("RADAD_WIDE_MIN_Q", "smallest batch that takes the 256-query tile scan (default 17)"); return e ? atoi(e) : SQ_NQ + 1; }();
+    bool use_hi = false, skipped_hi = false;
     int s_splits = 0;
+    const int ksel = k + margin;                 // list length of the fp32 tile kernels
+    // small batches (<= 16 queries: the online predict() search, pipeline.py:1038-1054, is ONE query of dim 5376 / 3584) stream the
+    // store; the kernels park only the nq queries handed over in LDS, so any dim goes as long as that block fits beside the slots
+    // (16 queries of dim 5376 do not: such a batch takes the tile kernels like a large one)
+    const size_t sq_slot_bytes = std::max<size_t>(sizeof(float2) * 4 * SQ_NQ * SQ_SLOTS, sizeof(u64) * 3 * SQ_NQ * 32) + sizeof(int) * 4 * SQ_NQ;
+    const size_t sq_lds_hi = sizeof(_Float16) * (size_t)nq * (h->dim + 8) + sq_slot_bytes;
+    const size_t sq_lds_f32 = sizeof(float) * (size_t)nq * (h->dim + 4) + sq_slot_bytes;
+    const bool sq_fits = nq <= SQ_NQ && ksel <= 32 &&
+                         ((!h->hi_off && h->dim % 64 == 0 && sq_lds_hi <= SQ_LDS_BUDGET) || (!h->f16 && h->dim % 32 == 0 && sq_lds_f32 <= SQ_LDS_BUDGET));
     // (k + margin <= 32: the admission floor is the (k + margin)-th best score of the sample; a lower floor would admit
     // more than the 8 slots per query and tile can take)
-    if (cert && nq >= wide_min_q && k + margin <= 32 && h->ntotal > 0 && h->dim % 64 == 0 && !h->hi_off) {
+    if (cert && (nq >= wide_min_q || !sq_fits) && k + margin <= 32 && h->ntotal > 0 && h->dim % 64 == 0 && !h->hi_off) {
         int wq, ws; int64_t wc;
         knn_geometry_wide(h->ntotal, nq, &wq, &ws, &wc);
         // the threshold pre-pass: one tile per workgroup, at most KW_SAMPLE_SPLITS tiles, 1/8 of the store and
@@ -2109,24 +2127,32 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         s_splits = std::min(s_splits, std::max(8, (KW_SAMPLE_BLOCKS / wq) / 8 * 8));
         static_assert(KW_SAMPLE_SPLITS * 8 <= 64 * THR_LISTS_PER_LANE, "k_thr_from_parts: lists per lane");
         if (s_splits >= 8) {
-            if (h->hi_skip > 0) --h->hi_skip;
+            if (h->hi_skip > 0) { --h->hi_skip; skipped_hi = true; }
             else if (knn_ensure_hi(h, st, true)) { use_hi = true; n_qtiles = wq; n_splits = ws; chunk_rows = wc; }
         }
     }
     if (!use_hi && cert && !knn_ensure_hi(h, st, false)) { radad_set_error("store statistics could not be computed"); return RADAD_EHIP; }
-    const int ksel = k + margin;                 // list length of the fp32 tile kernels
-    const bool smallq_geom = !use_hi && nq <= SQ_NQ && h->dim <= SQ_MAX_DIM && ksel <= 32 && h->ntotal > 0;
+    const bool smallq_geom = !use_hi && nq <= SQ_NQ && ksel <= 32 && h->ntotal > 0;
     // the small batch over the f16 plane (certified like the tile scan): stores the plane is kept for, or fp16 stores
-    static const int smallq_hi_on = [] { const char* e = getenv("RADAD_KNN_SMALLQ_HI"); return e ? atoi(e) : 1; }();
+    static const int smallq_hi_on = [] { const char* e = radad_env_override("RADAD_KNN_SMALLQ_HI", "0 makes small batches stream the fp32 rows instead of the f16 plane (twice the bytes)"); return e ? atoi(e) : 1; }();
     bool smallq_hi = false;
-    if (smallq_geom && cert && smallq_hi_on && h->dim % 64 == 0 && h->ntotal >= 16384 && !h->hi_off && h->hi_skip == 0)
-        smallq_hi = knn_ensure_hi(h, st, true);
-    const bool smallq = smallq_geom && !smallq_hi && !h->f16 && h->dim % 32 == 0;
+    if (smallq_geom && cert && smallq_hi_on && h->dim % 64 == 0 && h->ntotal >= 16384 && !h->hi_off && !skipped_hi &&
+        sq_lds_hi <= SQ_LDS_BUDGET) {
+        // (every search that would take a certified f16 kernel counts the skip down: a handle that only sees small batches after a
+        // mass rejection used to stay on the fp32 kernel for ever)
+        if (h->hi_skip > 0) --h->hi_skip;
+        else smallq_hi = knn_ensure_hi(h, st, true);
+    }
+    const bool smallq = smallq_geom && !smallq_hi && !h->f16 && h->dim % 32 == 0 && sq_lds_f32 <= SQ_LDS_BUDGET;
     int sq_rows_per_wave = 0;
     if (smallq || smallq_hi) {
-        const int64_t waves_wanted = 256 * 8;                                     // 8 waves (2 workgroups) per CU
-        int64_t rpw = ceil_div64(ceil_div64(h->ntotal, waves_wanted), 16) * 16;
-        rpw = std::max<int64_t>(rpw, 128);
+        // a wave streams >= 128 KB (128 rows at dim 512) so that its lists' hand-over stays small beside the stream, but no more
+        // rows than leave 8 waves for every CU; the lists of a query (one per workgroup) should fit the re-rank's staged form
+        const int64_t waves_wanted = 256 * 8;
+        const size_t rb = smallq_hi ? (size_t)h->dim * 2 : (size_t)h->dim * 4;
+        const int64_t rows_min = std::max<int64_t>(16, std::min<int64_t>(128, ceil_div64(ceil_div64(128 * 1024, (int64_t)rb), 16) * 16));
+        int64_t rpw = std::max<int64_t>(ceil_div64(ceil_div64(h->ntotal, waves_wanted), 16) * 16, rows_min);
+        while (rpw < 128 && ceil_div64(ceil_div64(h->ntotal, rpw), 4) * ksel > RF_STAGE_MAX) rpw += 16;
         sq_rows_per_wave = (int)rpw;
         n_splits = (int)ceil_div64(ceil_div64(h->ntotal, rpw), 4);                // workgroups of 4 waves = lists per query
         n_qtiles = 1;
@@ -2286,8 +2312,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         sp.uscale = (!h->f16 && h->metric == RADAD_METRIC_COSINE) ? 0x1p-14f : 1.0f;
         sp.ynorm = h->ynorm; sp.q = qh; sp.qscale = qscale; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel; sp.l2 = l2;
         sp.rows_per_wave = sq_rows_per_wave; sp.n_parts = n_splits; sp.part_score = ps; sp.part_idx = pi;
-        const size_t slot_bytes = std::max<size_t>(sizeof(float2) * 4 * SQ_NQ * SQ_SLOTS, sizeof(u64) * 3 * SQ_NQ * 32);
-        const size_t lds = sizeof(_Float16) * SQ_NQ * (h->dim + 8) + slot_bytes + sizeof(int) * 4 * SQ_NQ;
+        const size_t lds = sq_lds_hi;
         const dim3 sgrid((unsigned)n_splits);
         if (ksel <= 16) {
             RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_hi_smallq<16>),
@@ -2306,8 +2331,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         SmallQParams sp;
         sp.db = (const float*)h->rows; sp.ynorm = h->ynorm; sp.q = q_use; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel;
         sp.l2 = p.l2; sp.rows_per_wave = sq_rows_per_wave; sp.n_parts = n_splits; sp.part_score = ps; sp.part_idx = pi;
-        const size_t slot_bytes = std::max<size_t>(sizeof(float2) * 4 * SQ_NQ * SQ_SLOTS, sizeof(u64) * 3 * SQ_NQ * 32);
-        const size_t lds = sizeof(float) * SQ_NQ * (h->dim + 4) + slot_bytes + sizeof(int) * 4 * SQ_NQ;
+        const size_t lds = sq_lds_f32;
         const dim3 sgrid((unsigned)n_splits);
         if (ksel <= 16) {
             RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_f32_smallq<16>),
@@ -2379,16 +2403,17 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         x.slice_rows = ceil_div64(std::max<int64_t>(h->ntotal, 1), KX_SLICES);
         x.pkey = (double*)(ws + o_xk); x.pidx = (int*)(ws + o_xi); x.id_base = h->id_base;
         x.out_dist = out_dist_dev; x.out_idx = out_idx_dev; x.out_key = out_key_dev;
-        x.host_stats = h->host_count_dev;
+        x.host_stats = h->host_count_dev + 8 * cslot;
         const size_t xlds = (size_t)xgroup * h->dim * 4 + (size_t)KX_WAVES * xgroup * k * 12 + 16;
         RADAD_REQUIRE(xlds <= 160 * 1024, "radad_knn_search: dim %d x k %d too large for the exact kernel", h->dim, k);
         RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_exact_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
         hipLaunchKernelGGL(k_exact_scan, dim3(KX_SLICES, KX_GROUPS_Y), dim3(KX_THREADS), xlds, st, x);
         hipLaunchKernelGGL(k_exact_merge, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, x);
         RADAD_HIP_CHECK(hipGetLastError());
-        RADAD_HIP_CHECK(hipEventRecord(h->ev_count, st));      // (k_exact_merge has written the counters to the pinned host copy)
-        h->count_pending = true;
-        h->count_nq = nq;
+        RADAD_HIP_CHECK(hipEventRecord(h->ev_count[cslot], st));      // (k_exact_merge has written the counters to the pinned host copy)
+        h->count_pending[cslot] = true;
+        h->count_nq[cslot] = nq;
+        ++h->search_seq;
     }
     RADAD_HIP_CHECK(hipEventRecord(h->ev_done, st));
     h->done_recorded = true;
@@ -2485,8 +2510,9 @@ int radad_knn_last_recheck(radad_knn_t h, int* n_queries) {
     RADAD_REQUIRE(h && n_queries, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
-    if (h->count_pending) RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count));
-    *n_queries = h->host_count ? *h->host_count : 0;
+    const int ls = (int)((h->search_seq + 1) & 1);       // slot of the most recent certified search
+    if (h->count_pending[ls]) RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count[ls]));
+    *n_queries = (h->host_count && h->search_seq) ? h->host_count[8 * ls] : 0;
     return RADAD_OK;
 }
 
@@ -2494,9 +2520,10 @@ int radad_knn_last_certificate(radad_knn_t h, int64_t* n_queries, int* stats6) {
     RADAD_REQUIRE(h && stats6, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
-    if (h->count_pending) RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count));
-    for (int i = 0; i < 6; ++i) stats6[i] = h->host_count ? h->host_count[i] : 0;
-    if (n_queries) *n_queries = h->count_nq;
+    const int ls = (int)((h->search_seq + 1) & 1);       // slot of the most recent certified search
+    if (h->count_pending[ls]) RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count[ls]));
+    for (int i = 0; i < 6; ++i) stats6[i] = (h->host_count && h->search_seq) ? h->host_count[8 * ls + i] : 0;
+    if (n_queries) *n_queries = h->search_seq ? h->count_nq[ls] : 0;
     return RADAD_OK;
 }
 

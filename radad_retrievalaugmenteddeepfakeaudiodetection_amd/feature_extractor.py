@@ -132,6 +132,9 @@ class MelProjectionFeatureExtractor:
             n_clips = offs.numel() - 1
             if n_clips < 0:
                 raise ValueError("clip_offsets must hold at least one entry")
+            # device offsets cannot be checked here without a synchronisation: the plan kernel clamps them (no out-of-bounds
+            # read whatever the tensor holds) and flags what it repaired; the PREVIOUS batch's flags have long landed
+            self.check_device_plan(what="the previous device-offset batch")
             out = torch.empty((n_clips, self.output_dim), device=wave.device, dtype=out_dtype)
             with torch.cuda.device(wave.device):
                 _lib.check(self._lib.radad_embed_forward_dev(self._h, wave.data_ptr(), offs.data_ptr(), n_clips, wave.numel(),
@@ -148,6 +151,17 @@ class MelProjectionFeatureExtractor:
                                                         n_clips, out.data_ptr(), code, _lib.stream_ptr(wave.device)),
                        "radad_embed_forward")
         return out
+
+    def check_device_plan(self, what="the last device-offset batch"):
+        """ValueError if the segment-plan kernel had to repair the device-resident clip offsets of the most recent
+        embed_clips(wave, <CUDA offsets>) call (the host-offset path raises up front, as segmenter.py:18-19 does for bad
+        input).  Waits for that batch."""
+        f = C.c_int()
+        _lib.check(self._lib.radad_embed_plan_flags(self._h, C.byref(f)), "radad_embed_plan_flags")
+        if f.value:
+            why = [m for b, m in ((1, "offsets outside the wave buffer"), (2, "offsets not non-decreasing"),
+                                  (4, "more segments than the wave buffer can hold")) if f.value & b]
+            raise ValueError(f"clip_offsets of {what} were invalid ({', '.join(why)}); its embeddings are not those of the intended clips")
 
     def profile(self, enable: bool = True):
         _lib.check(self._lib.radad_embed_profile(self._h, 1 if enable else 0), "radad_embed_profile")

@@ -541,12 +541,11 @@ class VectorDatabase:
             if self.index is None:
                 logging.warning("No index to save.")
                 return
-            if isinstance(self.index, HipIVFFlatIndex):
-                # rows in insertion order as a NATIVE flat snapshot (streamed from HBM by radad_knn_save, no host copy of the
-                # store), centroids in a small sidecar; assignments are recomputed on load (deterministic: nearest centroid)
-                self.index.save(self.db_path)
-            else:
-                self.index.save(self.db_path)
+            # IVF: rows in insertion order as a NATIVE flat snapshot (streamed from HBM by radad_knn_save, no host copy of the
+            # store), centroids in a small sidecar; assignments are recomputed on load (deterministic: nearest centroid)
+            self.index.save(self.db_path)
+            if not isinstance(self.index, HipIVFFlatIndex) and os.path.exists(self.db_path + ".ivf.npz"):
+                os.remove(self.db_path + ".ivf.npz")      # centroids of an IVF store saved here earlier: not this store's
             meta = {"paths": self.vector_paths, "labels": self.vector_labels, "metadata": self.vector_metadata,
                     "index_type": self.config.vector_db_index_type, "dimension": self.index.d}
             with open(self.metadata_path, "wb") as f:
@@ -571,7 +570,10 @@ class VectorDatabase:
                 magic = f.read(8)
             if shard is not None and magic != b"RADADKNN":
                 raise ValueError("sharded load is only available for native flat snapshots")
-            if magic == b"RADADKNN" and os.path.exists(self.db_path + ".ivf.npz"):      # an IVF store written by save() above
+            # which kind of store the snapshot holds is what save() recorded (meta["index_type"]), not whether a centroid sidecar
+            # happens to lie beside it (files written before the key existed: the sidecar decides, as it used to)
+            saved_type = str(meta.get("index_type", "IVF" if os.path.exists(self.db_path + ".ivf.npz") else "")).upper()
+            if magic == b"RADADKNN" and saved_type == "IVF":      # an IVF store written by save() above
                 if shard is not None:
                     raise ValueError("sharded load is only available for flat stores")
                 self.create_index(int(meta["dimension"]))

@@ -166,3 +166,75 @@ def test_oracle_is_not_imported_by_the_product():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src.replace("oracle/synth.py", ""), f
+
+
+def test_load_follows_the_saved_index_type_not_a_stale_sidecar(tmp_path, monkeypatch):
+    """IVF save -> flat save to the same directory -> load: the flat save removes the centroid sidecar of the earlier IVF
+    store, and load() picks its branch from meta['index_type'] (it used to see the stale sidecar, build a flat index, raise
+    'saved IVF store does not match config' into its own log-and-degrade handler and come back silently EMPTY).  Host logic
+    only: the two index classes are stand-ins that write / read the native snapshot's magic (no GPU here)."""
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import vector_database as V
+
+    class FakeFlat:
+        def __init__(self, d, metric, device=0, id_base=0, store_f16=False):
+            self.d, self.metric, self.id_base, self.store_f16, self.ntotal = d, metric, id_base, store_f16, 0
+        def add(self, x):
+            self.ntotal += len(x)
+        def save(self, path):
+            with open(path, "wb") as f:
+                f.write(b"RADADKNN" + np.int64(self.ntotal).tobytes())
+        def load(self, path, row0=0, n_rows=-1):
+            raw = open(path, "rb").read()
+            assert raw[:8] == b"RADADKNN"
+            self.ntotal = int(np.frombuffer(raw[8:16], np.int64)[0]) if n_rows < 0 else n_rows
+        @staticmethod
+        def snapshot_info(path):
+            raw = open(path, "rb").read()
+            return {"d": 8, "metric": 0, "store_f16": False, "ntotal": int(np.frombuffer(raw[8:16], np.int64)[0])}
+
+    class FakeIVF(FakeFlat):
+        def __init__(self, d, nlist, device=0):
+            FakeFlat.__init__(self, d, 0)
+            self.nlist, self.is_trained = nlist, True
+        def save(self, path):
+            FakeFlat.save(self, path)
+            with open(path + ".ivf.npz", "wb") as f:
+                np.savez(f, kind="radad_ivf", ntotal=self.ntotal)
+        def load(self, path):
+            assert os.path.exists(path + ".ivf.npz")
+            FakeFlat.load(self, path)
+
+    monkeypatch.setattr(V, "HipFlatIndex", FakeFlat)
+    monkeypatch.setattr(V, "HipIVFFlatIndex", FakeIVF)
+    c = _cfg()
+    c.vector_db_path = str(tmp_path)
+    rows = np.zeros((12, 8), np.float32)
+    names = [f"f{i}.wav" for i in range(12)]
+
+    c.vector_db_index_type = "IVF"
+    a = V.VectorDatabase(c)
+    a.add_vectors(rows, names, [0] * 12, {})
+    a.save()
+    assert os.path.exists(a.db_path + ".ivf.npz")
+    b = V.VectorDatabase(c)
+    b.load()
+    assert isinstance(b.index, FakeIVF) and b.index.ntotal == 12
+
+    c.vector_db_index_type = "L2"                      # rebuild as a flat store, save to the same path
+    f = V.VectorDatabase(c)
+    f.add_vectors(rows[:7], names[:7], [1] * 7, {})
+    f.save()
+    assert not os.path.exists(f.db_path + ".ivf.npz"), "the flat save must drop the earlier IVF store's sidecar"
+    g = V.VectorDatabase(c)
+    g.load()
+    assert type(g.index) is FakeFlat and g.index.ntotal == 7 and len(g.vector_paths) == 7
+    s = V.VectorDatabase(c)
+    s.load(shard=(1, 2))                               # a row shard of the flat snapshot loads as well
+    assert type(s.index) is FakeFlat and s.index.ntotal in (3, 4) and len(s.vector_paths) == s.index.ntotal
+
+    # even with a stale sidecar lying around (written by a build without the fix), the recorded type decides
+    with open(f.db_path + ".ivf.npz", "wb") as fh:
+        np.savez(fh, kind="radad_ivf", ntotal=12)
+    g2 = V.VectorDatabase(c)
+    g2.load()
+    assert type(g2.index) is FakeFlat and g2.index.ntotal == 7
