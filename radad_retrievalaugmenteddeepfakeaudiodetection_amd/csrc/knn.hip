@@ -792,11 +792,13 @@ struct SmallQHiParams {
     const _Float16* db;         // [n][dim] f16 rows
     const float* rscale;        // [n] per-row scale, or nullptr: uscale for every row
     float uscale;
-    const float* ynorm;         // [n] |y|^2 (L2)
-    const _Float16* q;          // [nq][dim] f16 queries (scaled per query)
+    const float* rbias;         // [n] per-row bias magnitude (|y'|^2 for L2, mu.y for a centred IP / cosine plane), or nullptr
+    float bias_sign, mult;      // score = mult a + bias_sign rbias[row] + qconst[query]   (knn_hi.inc, RSC 2)
+    const float* qconst;        // [nq] or nullptr
+    const _Float16* q;          // [nq][dim] f16 queries (scaled per query; centred when the plane is)
     const float* qscale;        // [nq]
     int64_t n;
-    int nq, dim, k, l2;
+    int nq, dim, k;
     int rows_per_wave;          // multiple of 16
     int n_parts;                // workgroups = lists per query
     float* part_score; int* part_idx;   // [nq, n_parts, k]
@@ -830,7 +832,8 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams 
 #pragma unroll
     for (int j = 0; j < KSEL; ++j) lst[j] = SENT;
     float thr = -INFINITY;               // threshold of query (lane & 15), refreshed from the owner lane
-    const float qs = r16 < p.nq ? p.qscale[r16] : 0.f;
+    const float qs = r16 < p.nq ? p.qscale[r16] * p.mult : 0.f;
+    const float qc = (r16 < p.nq && p.qconst) ? p.qconst[r16] : 0.f;
     // lane (r16, g) holds elements 32 kb + 8 g .. + 7 of row r16 (A) and of query r16 (B): one load instruction reads 64
     // contiguous bytes of each of its 16 rows, two consecutive ones a whole 128-byte line
     const _Float16* qrow = sQ + min(r16, p.nq - 1) * qld + 8 * g;   // columns >= nq repeat the last query (never admitted below)
@@ -845,7 +848,7 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams 
         for (int e = 0; e < 4; ++e) {
             const int64_t row = min(row0 + 4 * g + e, p.n - 1);
             rs[e] = p.rscale ? p.rscale[row] : p.uscale;
-            yn[e] = p.l2 ? p.ynorm[row] : 0.f;
+            yn[e] = p.rbias ? p.bias_sign * p.rbias[row] + qc : qc;
         }
         constexpr int PKB = KSEL <= 16 ? 16 : 8;      // K blocks per panel (the 32-entry lists leave fewer registers)
         for (int kp = 0; kp < nkb; kp += PKB) {
@@ -867,8 +870,7 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int64_t row = row0 + 4 * g + e;
-            float sc = (acc0[e] + acc1[e]) * rs[e] * qs;
-            if (p.l2) sc = 2.f * sc - yn[e];
+            const float sc = fmaf((acc0[e] + acc1[e]) * rs[e], qs, yn[e]);
             if (row < w_end && r16 < p.nq && sc >= thr) {
                 const int sl = atomicAdd(&myCnt[r16], 1);          // < SQ_SLOTS by construction (4 x 4 lanes)
                 myCand[r16 * SQ_SLOTS + sl] = make_float2(sc, __int_as_float((int)row));
@@ -1758,8 +1760,13 @@ struct radad_knn_s {
     float* rscale = nullptr;     // [hi_cap] 2^-e per row (nullptr for cosine stores: one scale, 2^-14)
     int64_t hi_rows = 0, hi_cap = 0;
     int hi_off = 0;              // 1: disabled (RADAD_KNN_HI=0, or its allocation failed)
-    unsigned* stat = nullptr;    // device [2] float bits: max |y|, max |y - yh| over rows [0, stat_rows)
+    unsigned* stat = nullptr;    // device [3] float bits: max |y'|, max |y' - yh| (y' = y - mu when the plane is centred, else y) and
+                                 // max |y| over rows [0, stat_rows)
     int64_t stat_rows = 0;
+    // centred plane (decided when the plane is built, from the rows the store holds then): the plane holds f16((y - mu) 2^e)
+    float* cmu = nullptr;        // [dim] the common component, or nullptr: plane of the rows themselves
+    float mu_norm = 0.f;         // |mu|
+    float* rbias = nullptr;      // [hi_cap] per-row bias of a centred plane: |y - mu|^2 (L2) or mu.y (IP / cosine)
     // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
     // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
     // The counters of search i land in slot i % 2 and are CONSUMED by search i + 2 behind a wait on that slot's event (long due by
@@ -1784,6 +1791,8 @@ struct radad_knn_s {
     std::mutex mu;
 };
 
+static void knn_drop_plane(radad_knn_t h);
+
 static int knn_realloc(radad_knn_t h, int64_t cap) {
     char* nrows = nullptr;
     float* nnorm = nullptr;
@@ -1806,9 +1815,7 @@ static int knn_realloc(radad_knn_t h, int64_t cap) {
     h->rows = nrows;
     h->ynorm = nnorm;
     h->capacity = cap;
-    if (h->hi) (void)hipFree(h->hi);             // rebuilt lazily for the new capacity
-    if (h->rscale) (void)hipFree(h->rscale);
-    h->hi = nullptr; h->rscale = nullptr; h->hi_rows = 0; h->hi_cap = 0;
+    knn_drop_plane(h);                           // rebuilt lazily for the new capacity
     return RADAD_OK;
 }
 
@@ -1832,30 +1839,115 @@ static int knn_workspace(radad_knn_t h, size_t bytes) {
     return RADAD_OK;
 }
 
+// column means of the first `m` rows, deterministic: KM_SLICES partial sums per column in fixed order, then one block adds them
+// up, and measures |mu|^2 against the rows' mean |y|^2 (out2[0], out2[1]) for the host's decision
+constexpr int KM_SLICES = 64;
+__global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ rows, int64_t m, int dim, float* __restrict__ part /*[KM_SLICES][dim + 1]*/) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int64_t per = (m + KM_SLICES - 1) / KM_SLICES;
+    const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(r0 + per, m);
+    float s = 0.f, ss = 0.f;
+    if (c < dim)
+        for (int64_t r = r0; r < r1; ++r) { const float v = rows[r * dim + c]; s += v; ss = fmaf(v, v, ss); }
+    if (c < dim) part[(int64_t)blockIdx.y * (dim + 1) + c] = s;
+    // sum of squares of this block's columns and rows -> one value per (slice, column block), added up by k_col_final
+    __shared__ float red[256];
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) part[(int64_t)KM_SLICES * (dim + 1) + blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void k_col_final(const float* __restrict__ part, int64_t m, int dim, int n_cblocks, float* __restrict__ mu,
+                                                   float* __restrict__ out2) {
+    __shared__ float red[256];
+    float mm = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        float s = 0.f;
+        for (int sl = 0; sl < KM_SLICES; ++sl) s += part[(int64_t)sl * (dim + 1) + c];
+        const float v = s / (float)m;
+        mu[c] = v;
+        mm = fmaf(v, v, mm);
+    }
+    red[threadIdx.x] = mm;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const float mu2 = red[0];
+    __syncthreads();
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < KM_SLICES * n_cblocks; i += 256) ss += part[(int64_t)KM_SLICES * (dim + 1) + i];
+    red[threadIdx.x] = ss;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { out2[0] = mu2; out2[1] = red[0] / (float)m; }
+}
+
+static void knn_drop_plane(radad_knn_t h) {
+    if (h->hi) (void)hipFree(h->hi);
+    if (h->rscale) (void)hipFree(h->rscale);
+    if (h->cmu) (void)hipFree(h->cmu);
+    if (h->rbias) (void)hipFree(h->rbias);
+    h->hi = nullptr; h->rscale = nullptr; h->cmu = nullptr; h->rbias = nullptr; h->mu_norm = 0.f;
+    h->hi_rows = 0; h->hi_cap = 0;
+}
+
+// Decide whether the plane is CENTRED and compute mu (one-off, when the plane is built; synchronises).  Centred when the common
+// component carries a noticeable part of the rows' energy (|mu|^2 >= 2 % of the mean |y|^2): pooled encoder embeddings do (all
+// positive activations around a shared mean), random directions do not -- and an un-centred cosine plane keeps its one scale for
+// the whole store, i.e. the scan variant without any per-score arithmetic.
+constexpr int64_t KM_MAX_ROWS = 65536;
+constexpr float KM_CENTRE_FRACTION = 0.02f;
+static bool knn_choose_centre(radad_knn_t h, hipStream_t st) {
+    const int64_t m = std::min<int64_t>(h->ntotal, KM_MAX_ROWS);
+    if (m < 64 || h->f16) return false;
+    static const int centre_env = [] { const char* e = radad_env_override("RADAD_KNN_CENTRE", "0 never centres the f16 plane, 1 always does (default: decided per store from |mean|^2 / mean |y|^2)"); return e ? atoi(e) : -1; }();
+    if (centre_env == 0) return false;
+    const int ncb = (h->dim + 255) / 256;
+    float *part = nullptr, *mu = nullptr, *out2 = nullptr;
+    const size_t pbytes = ((size_t)KM_SLICES * (h->dim + 1) + (size_t)KM_SLICES * ncb) * sizeof(float);
+    bool ok = hipMalloc(&part, pbytes) == hipSuccess && hipMalloc(&mu, (size_t)h->dim * sizeof(float)) == hipSuccess &&
+              hipMalloc(&out2, 2 * sizeof(float)) == hipSuccess;
+    float host2[2] = {0.f, 1.f};
+    if (ok) {
+        hipLaunchKernelGGL(k_col_partial, dim3(ncb, KM_SLICES), dim3(256), 0, st, (const float*)h->rows, m, h->dim, part);
+        hipLaunchKernelGGL(k_col_final, dim3(1), dim3(256), 0, st, (const float*)part, m, h->dim, ncb, mu, out2);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(host2, out2, sizeof(host2), hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+    }
+    if (part) (void)hipFree(part);
+    if (out2) (void)hipFree(out2);
+    const bool centre = ok && (centre_env == 1 || host2[0] >= KM_CENTRE_FRACTION * host2[1]) && host2[0] > 0.f && host2[0] < INFINITY;
+    if (!centre) { if (mu) (void)hipFree(mu); (void)hipGetLastError(); return false; }
+    h->cmu = mu;
+    h->mu_norm = sqrtf(host2[0]) * (1.0f + 0x1p-10f);
+    return true;
+}
+
 // store statistics (max |y|, max |y - yh|) and, when wanted, the f16 hi plane, brought up to date with the rows
 // (appends only touch the new rows).  Returns false when the plane was wanted but is not available.
 static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
     if (!h->stat) {
-        if (hipMalloc(&h->stat, 2 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
-        (void)hipMemsetAsync(h->stat, 0, 2 * sizeof(unsigned), st);
+        if (hipMalloc(&h->stat, 3 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        (void)hipMemsetAsync(h->stat, 0, 3 * sizeof(unsigned), st);
         h->stat_rows = 0;
     }
     const bool plane = want_plane && !h->hi_off && !h->f16 && h->dim % 64 == 0;
     if (plane && (h->hi_cap != h->capacity || !h->hi)) {
         (void)hipDeviceSynchronize();
-        if (h->hi) (void)hipFree(h->hi);
-        if (h->rscale) (void)hipFree(h->rscale);
-        h->hi = nullptr; h->rscale = nullptr; h->hi_rows = 0; h->hi_cap = 0;
-        const bool per_row = h->metric != RADAD_METRIC_COSINE;
+        knn_drop_plane(h);
+        const bool centred = knn_choose_centre(h, st);
+        const bool per_row = h->metric != RADAD_METRIC_COSINE || centred;
         if (hipMalloc(&h->hi, (size_t)h->capacity * h->dim * 2) != hipSuccess ||
-            (per_row && hipMalloc(&h->rscale, (size_t)h->capacity * sizeof(float)) != hipSuccess)) {
+            (per_row && hipMalloc(&h->rscale, (size_t)h->capacity * sizeof(float)) != hipSuccess) ||
+            (centred && hipMalloc(&h->rbias, (size_t)h->capacity * sizeof(float)) != hipSuccess)) {
             (void)hipGetLastError();
-            if (h->hi) (void)hipFree(h->hi);
-            h->hi = nullptr; h->rscale = nullptr;
+            knn_drop_plane(h);
             h->hi_off = 1;              // no room for the plane: stay on the fp32 kernels
         } else {
             h->hi_cap = h->capacity;
         }
+        // the statistics describe the operands of the plane (y - mu when centred): start them over with it
+        (void)hipMemsetAsync(h->stat, 0, 3 * sizeof(unsigned), st);
+        h->stat_rows = 0;
     }
     const bool have_plane = plane && h->hi;
     const int64_t from = have_plane ? std::min(h->hi_rows, h->stat_rows) : h->stat_rows;
@@ -1867,10 +1959,13 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
         hp.stat_max = h->stat; hp.eps_out = nullptr; hp.ystat = nullptr;
         hp.norm_out = nullptr; hp.zero_flags = nullptr; hp.zero_counters = nullptr;
         hp.n = h->ntotal - from; hp.dim = h->dim;
-        // cosine rows have |x| <= 1: one scale for the whole store (no per-score arithmetic in the scan);
+        // un-centred cosine rows have |x| <= 1: one scale for the whole store (no per-score arithmetic in the scan);
         // an fp16 store is its own plane: statistics only, un-scaled
-        hp.fixed_e = h->f16 ? 0 : (h->metric == RADAD_METRIC_COSINE ? 14 : HI_E_PER_ROW);
-        hp.l2 = 0; hp.exact_ops = h->f16 ? 1 : 0;
+        hp.fixed_e = h->f16 ? 0 : ((h->metric == RADAD_METRIC_COSINE && !h->cmu) ? 14 : HI_E_PER_ROW);
+        hp.l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0; hp.exact_ops = h->f16 ? 1 : 0;
+        // (a plane that exists keeps its centring for the statistics-only calls too: the statistics are those of ITS operands)
+        hp.mu = h->cmu; hp.mu_norm = h->mu_norm; hp.biased = 0;
+        hp.bias_out = (have_plane && h->rbias) ? h->rbias + from : nullptr; hp.qconst_out = nullptr;
         hipLaunchKernelGGL(k_hi_rows, dim3((unsigned)ceil_div64(hp.n, 4)), dim3(256), 0, st, hp);
         if (hipGetLastError() != hipSuccess) return false;
         h->stat_rows = h->ntotal;
@@ -1945,6 +2040,8 @@ int radad_knn_destroy(radad_knn_t h) {
         if (h->ws) (void)hipFree(h->ws);
         if (h->hi) (void)hipFree(h->hi);
         if (h->rscale) (void)hipFree(h->rscale);
+        if (h->cmu) (void)hipFree(h->cmu);
+        if (h->rbias) (void)hipFree(h->rbias);
         if (h->stat) (void)hipFree(h->stat);
         if (h->host_count) (void)hipHostFree(h->host_count);
         for (int i = 0; i < 2; ++i) if (h->ev_count[i]) (void)hipEventDestroy(h->ev_count[i]);
@@ -2183,6 +2280,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     const size_t o_qn = off; off += b_qn;
     const size_t o_qh = off; off += b_qh;
     const size_t o_qscale = off; off += b_vec;
+    const size_t o_qconst = off; off += b_vec;
     const size_t o_eps = off; off += b_vec;
     const size_t o_thr = off; off += b_vec;
     const size_t o_qflag = off; off += b_vec;          // qflag [nq] int
@@ -2200,6 +2298,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     char* ws = (char*)h->ws;
     _Float16* qh = (_Float16*)(ws + o_qh);
     float* qscale = (float*)(ws + o_qscale);
+    float* qconst = (float*)(ws + o_qconst);
     float* eps = (float*)(ws + o_eps);
     float* thr_init = (float*)(ws + o_thr);
     int* qflag = (int*)(ws + o_qflag);
@@ -2218,6 +2317,8 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         q_use = qf;
     }
     const bool hi_q = use_hi || smallq_hi;                 // f16 queries with a per-query scale
+    const float* mu = (hi_q && !h->f16) ? h->cmu : nullptr; // centred plane: the queries are centred the same way
+    const bool biased = hi_q && (l2 || mu);                // the scale + bias variant of the f16 kernels (RSC 2)
     const bool prep = cert || use_hi || f16_tile;          // k_hi_rows runs: it also normalises and clears the flags
     if (h->metric == RADAD_METRIC_COSINE) {
         float* qn = (float*)(ws + o_qn);
@@ -2236,6 +2337,8 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         hp.l2 = l2; hp.exact_ops = (hi_q || f16_tile) ? 0 : 1;
         hp.norm_out = h->metric == RADAD_METRIC_COSINE ? (float*)(ws + o_qn) : nullptr;
         hp.zero_flags = cert ? qflag : nullptr; hp.zero_counters = cert ? flag_count : nullptr;
+        hp.mu = mu; hp.mu_norm = mu ? h->mu_norm : 0.f; hp.biased = (biased || (f16_tile && l2)) ? 1 : 0;
+        hp.bias_out = nullptr; hp.qconst_out = biased ? qconst : nullptr;
         hipLaunchKernelGGL(k_hi_rows, dim3(rgrid), dim3(256), 0, st, hp);
     }
     if (h->metric == RADAD_METRIC_COSINE) q_use = (const float*)(ws + o_qn);
@@ -2253,7 +2356,9 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         wp.db = h->f16 ? (const void*)h->rows : (const void*)h->hi;
         wp.rscale = h->f16 ? nullptr : h->rscale;
         wp.uscale = (!h->f16 && h->metric == RADAD_METRIC_COSINE) ? 0x1p-14f : 1.0f;
-        wp.ynorm = h->ynorm; wp.q = qh; wp.qscale = qscale;
+        // bias of the scale + bias variant: a centred plane has its own (|y - mu|^2 or mu.y); un-centred L2 uses |y|^2 as stored
+        wp.rbias = mu ? h->rbias : h->ynorm; wp.bias_sign = l2 ? -1.f : 1.f; wp.mult = l2 ? 2.f : 1.f; wp.qconst = biased ? qconst : nullptr;
+        wp.q = qh; wp.qscale = qscale;
         wp.n = h->ntotal; wp.nq = (int)nq; wp.row_bytes = h->dim * 2; wp.l2 = l2;
         wp.n_qtiles = n_qtiles; wp.n_splits = n_splits; wp.chunk_rows = chunk_rows; wp.part_score = ps; wp.part_idx = pi;
         wp.thr_init = nullptr; wp.qflag = qflag;
@@ -2269,7 +2374,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
             }
         }
 #endif
-        const int rsc = l2 ? 2 : (wp.rscale ? 1 : 0);
+        const int rsc = biased ? 2 : (wp.rscale ? 1 : 0);
         const size_t lds = knn_hi_lds_bytes();
         const void* fns[3] = {reinterpret_cast<const void*>(k_knn_hi<0>), reinterpret_cast<const void*>(k_knn_hi<1>),
                               reinterpret_cast<const void*>(k_knn_hi<2>)};
@@ -2310,7 +2415,9 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         sp.db = h->f16 ? (const _Float16*)h->rows : h->hi;
         sp.rscale = h->f16 ? nullptr : h->rscale;
         sp.uscale = (!h->f16 && h->metric == RADAD_METRIC_COSINE) ? 0x1p-14f : 1.0f;
-        sp.ynorm = h->ynorm; sp.q = qh; sp.qscale = qscale; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel; sp.l2 = l2;
+        sp.rbias = biased ? (mu ? h->rbias : h->ynorm) : nullptr; sp.bias_sign = l2 ? -1.f : 1.f; sp.mult = l2 ? 2.f : 1.f;
+        sp.qconst = biased ? qconst : nullptr;
+        sp.q = qh; sp.qscale = qscale; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel;
         sp.rows_per_wave = sq_rows_per_wave; sp.n_parts = n_splits; sp.part_score = ps; sp.part_idx = pi;
         const size_t lds = sq_lds_hi;
         const dim3 sgrid((unsigned)n_splits);
@@ -2637,7 +2744,7 @@ int snap_load_range(radad_knn_t h, const char* path, int64_t row0, int64_t n_row
     RADAD_HIP_CHECK(hipDeviceSynchronize());
     h->ntotal = 0;
     h->hi_rows = 0; h->stat_rows = 0;      // the hi plane and the statistics describe the old contents
-    if (h->stat) RADAD_HIP_CHECK(hipMemset(h->stat, 0, 2 * sizeof(unsigned)));
+    if (h->stat) RADAD_HIP_CHECK(hipMemset(h->stat, 0, 3 * sizeof(unsigned)));
     if ((rc = knn_grow(h, n_rows))) return rc;
     const unsigned char* src = map.base + hd.payload_off + (size_t)row0 * rb;
     const size_t total = (size_t)n_rows * rb;
