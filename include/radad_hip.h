@@ -111,6 +111,19 @@ int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, f
 #define RADAD_Q_BF16 1
 int radad_knn_search_ex(radad_knn_t h, const void* q_dev, int q_dtype, int64_t nq, int k, float* out_dist_dev,
                         int64_t* out_idx_dev, double* out_key_dev, void* stream);
+/* The same search in two halves, for a store that is ROW-SHARDED over several GPUs (the reference is single-GPU,
+ * vector_database.py:23; sharding is this build's, north_star).  _begin prepares the queries and scans this shard; it writes to
+ * kth_lower_bound_dev [nq] a lower bound of the exact k-th best score of THIS shard per query (scores: q.y for inner product /
+ * cosine, -|q - y|^2 for L2; -inf when the scan that ran offers none).  The caller takes the element-wise MAXIMUM over all shards
+ * (one all-reduce of 4 nq bytes) and hands it to _finish, which then re-ranks in float64 only the candidates that can still be among
+ * the GLOBAL k best -- instead of every shard certifying its own top k, 8 x the work of one GPU on 8 shards.  With a bound the rows
+ * a shard returns are those of its rows that can be in the global top k (fewer than k is normal; the rest is -1 filled); merged over
+ * the shards (radad_topk_merge_f64) the result is exactly the unsharded search's.  global_lower_bound_dev == NULL: _finish
+ * returns this shard's own top k, i.e. _begin + _finish == radad_knn_search_ex.  One begun search per handle at a time; other
+ * searches on the handle fail until it is finished. */
+int radad_knn_search_begin(radad_knn_t h, const void* q_dev, int q_dtype, int64_t nq, int k, float* kth_lower_bound_dev, void* stream);
+int radad_knn_search_finish(radad_knn_t h, const float* global_lower_bound_dev, float* out_dist_dev, int64_t* out_idx_dev,
+                            double* out_key_dev, void* stream);
 /* host-buffer variant (what index.search(np.ndarray, k) does); synchronous */
 int radad_knn_search_host(radad_knn_t h, const float* q_host, int64_t nq, int k, float* out_dist_host,
                           int64_t* out_idx_host);
@@ -138,11 +151,15 @@ int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, i
 #define RADAD_SCAN_HI_SMALLQ 3    /* <= 16 queries, f16 plane / fp16 store streamed (2 bytes per element), certified */
 #define RADAD_SCAN_F16_TILE 4     /* fp16 store on the fp16-MFMA tile kernel without the certificate path */
 int radad_knn_last_scan_kind(radad_knn_t h, int* kind);
+/* scan-kernel launches of the last search (the certified tile scan covers a large store in two: the first eighth with the
+ * sample's admission floor, the rest with the floor the first eighth's candidates give); radad_knn_profile_read has one entry each */
+int radad_knn_last_scan_launches(radad_knn_t h, int* n_launches);
 /* Certificate of the most recent search (see radad_knn_search_f64): number of queries the float64 re-rank could NOT certify
  * and that were therefore searched again by the exact float64 kernel (results are exact either way).  Synchronises with
  * that search.  radad_knn_last_certificate additionally returns the batch size and stats6 = {rejected queries, sum over
- * the batch of candidates re-scored in float64, rejections because: the candidate buffer was full, a chunk's list was used
- * up, the scan's admission floor was above the threshold, the scan dropped a candidate}. */
+ * the batch of candidates re-scored in float64, rejections because: more than 512 candidates within the error bound, the scan's
+ * candidate buffer (or a chunk's list, on the fp32 kernels) overflowed, the scan's admission floor was above the threshold, the
+ * scan dropped a candidate}. */
 int radad_knn_last_recheck(radad_knn_t h, int* n_queries);
 int radad_knn_last_certificate(radad_knn_t h, int64_t* n_queries, int* stats6);
 

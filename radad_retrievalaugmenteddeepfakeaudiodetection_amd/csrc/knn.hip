@@ -943,6 +943,8 @@ struct RefineParams {
     const float* eps;         // [nq] error bound of the scan scores, or nullptr = legacy mode (exactly `cap` candidates)
     const float* thr_init;    // optional [nq]: admission floor of the scan (rows below it were never listed)
     const int* qflag;         // optional [nq]: the scan dropped a candidate of this query
+    const int* part_cnt;      // optional [nq] (emit-mode scan, n_parts == 1): entries filled in the query's buffer; > part_len = overflow
+    const float* global_lb;   // optional [nq] (sharded search): the best lower bound any shard has of the exact k-th best score
     int* flag_count;          // certified mode: [1] number of uncertified queries (atomicAdd) ...
     int* flag_sel;            // ... and their indices, in arrival order
     int* stats;               // optional [5]: sum of candidates re-scored, queries rejected for: buffer full / list used up /
@@ -974,6 +976,84 @@ constexpr size_t refine_lds_bytes(int cap) { return (size_t)cap * 20 + 256; }   
 // copy.  The unstaged form walks the lists in global memory: every round's winner re-reads its list head and every list is
 // walked entry by entry, i.e. 30-50 DEPENDENT trips to L2/HBM per query -- 0.17 ms for 1024 queries that re-score 150 rows
 // each, where the re-scoring itself needs a tenth of that.
+// The k-th largest of the NE scores staged in LDS (e_sc; -inf = "no entry", the smallest key), by a 4-pass radix select on the
+// order-preserving image of the float bits.  Only the VALUE is found.  Called by all RF_THREADS (= 256 = the bins) threads of the
+// block; hist [256] and xchg [2] are LDS scratch; e_sc needs no barrier of its own (the first pass's publishes it; so does the
+// early exit).  Returns -inf when NE < k.
+__device__ __forceinline__ float radix_select_kth(const float* e_sc, int NE, int k, int* hist, int* xchg) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    auto okey = [](float v) { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+    unsigned prefix = 0, pmask = 0;
+    int krem = k;
+    const bool have_k = NE >= k;                                         // (block-uniform)
+    for (int shift = 24; shift >= 0 && have_k; shift -= 8) {
+        hist[tid] = 0;                                                   // RF_THREADS == 256 bins
+        __syncthreads();                                                 // (first pass: also publishes e_sc)
+        for (int i = tid; i < NE; i += RF_THREADS) {
+            const unsigned key = okey(e_sc[i]);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (wave == 0) {                                                 // the digit that holds the krem-th largest matching key
+            int c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = hist[4 * lane + j];
+            const int s4 = c[0] + c[1] + c[2] + c[3];
+            int incl = s4;                                               // matching keys in this lane's bins and all higher ones
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_down(incl, o, 64);
+                if (lane + o < 64) incl += t;
+            }
+            int above = incl - s4;
+            if (above < krem && krem <= incl) {                          // exactly one lane
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {
+                    if (above + c[j] >= krem) { xchg[0] = 4 * lane + j; xchg[1] = krem - above; break; }
+                    above += c[j];
+                }
+            }
+        }
+        __syncthreads();
+        prefix |= (unsigned)xchg[0] << shift;
+        pmask |= 255u << shift;
+        krem = xchg[1];
+    }
+    if (!have_k) { __syncthreads(); return -INFINITY; }                  // publishes e_sc all the same
+    const unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
+    return __uint_as_float(u);
+}
+
+// k_kth_floor: between the two phases of the certified tile scan (and, for a sharded search, after it).  One workgroup per query:
+// a_k = the k-th best score among the candidates emitted so far (-inf when there are fewer than k, or the buffer overflowed).
+//   floor_io  (optional) [nq]: raised to a_k - 2 eps -- a score k rows are KNOWN to reach, lowered by the scan's error on both
+//             sides: every row of the exact top-k scores at least that, so the rest of the store is scanned with it;
+//   lb_out    (optional) [nq]: a_k - eps, a lower bound of the EXACT k-th best score of this store (shards exchange its maximum).
+struct KthParams {
+    const float* score;        // [nq][cap]
+    const int* cnt;            // [nq]
+    int cap, k;
+    const float* eps;          // [nq]
+    float* floor_io;
+    float* lb_out;
+};
+__global__ __launch_bounds__(RF_THREADS) void k_kth_floor(KthParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_k[];
+    float* e_sc = reinterpret_cast<float*>(smem_k);                      // [cap]
+    int* hist = reinterpret_cast<int*>(e_sc + p.cap);                    // [256]
+    int* xchg = hist + 256;
+    const int64_t q = blockIdx.x;
+    const int c = p.cnt[q];
+    const int NE = c <= p.cap ? c : 0;                                   // an overflowed buffer proves nothing (its query is rejected)
+    for (int i = threadIdx.x; i < NE; i += RF_THREADS) e_sc[i] = p.score[q * p.cap + i];
+    const float a_k = radix_select_kth(e_sc, NE, p.k, hist, xchg);
+    if (threadIdx.x == 0) {
+        const float e = p.eps[q];
+        if (p.floor_io && a_k > -INFINITY) p.floor_io[q] = fmaxf(p.floor_io[q], a_k - 2.f * e);
+        if (p.lb_out) p.lb_out[q] = a_k > -INFINITY ? a_k - e : -INFINITY;
+    }
+}
+
 template <bool STAGED>
 __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
@@ -998,68 +1078,36 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     const int dropped_q = (cert && p.qflag) ? p.qflag[q] : 0;
 
   if constexpr (STAGED) {
-    const int NE = p.n_parts * p.part_len;
+    // (emit-mode scan: ONE unsorted buffer of part_len entries per query, of which part_cnt[q] are filled -- more means overflow)
+    const int filled = p.part_cnt ? p.part_cnt[q] : 0;
+    const int NE = p.part_cnt ? min(filled, p.part_len) : p.n_parts * p.part_len;
     const int64_t ebase = qbase * p.part_len;
-    int* hist = e_id + NE;                                               // [256] digit histogram of the radix select
+    int* hist = e_id + p.n_parts * p.part_len;                           // [256] digit histogram of the radix select
     for (int i = tid; i < NE; i += RF_THREADS) {
         const int id = p.idx[ebase + i];
         const float sc = p.score[ebase + i];
         e_id[i] = id;
         e_sc[i] = id != IDX_SENTINEL ? sc : -INFINITY;
     }
-    // a_k = the k-th largest scan score, by a 4-pass radix select on the order-preserving image of the float bits (sentinels are
-    // -inf, the smallest key).  Only the VALUE is needed: every entry >= tau = a_k - 2 eps is re-scored, the k best among them;
-    // the first version found the k best one by one (k rounds of a block-wide arg-max, two barriers each: 40 % of this kernel).
-    auto okey = [](float v) { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
-    unsigned prefix = 0, pmask = 0;
-    int krem = p.k;
-    bool have_k = NE >= p.k;                                             // (block-uniform)
-    for (int shift = 24; shift >= 0 && have_k; shift -= 8) {
-        hist[tid] = 0;                                                   // RF_THREADS == 256 bins
-        __syncthreads();                                                 // (first pass: also publishes e_sc / e_id)
-        for (int i = tid; i < NE; i += RF_THREADS) {
-            const unsigned key = okey(e_sc[i]);
-            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
-        }
-        __syncthreads();
-        if (wave == 0) {                                                 // the digit that holds the krem-th largest matching key
-            int c[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c[j] = hist[4 * lane + j];
-            const int s4 = c[0] + c[1] + c[2] + c[3];
-            int incl = s4;                                               // matching keys in this lane's bins and all higher ones
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_down(incl, o, 64);
-                if (lane + o < 64) incl += t;
-            }
-            int above = incl - s4;
-            if (above < krem && krem <= incl) {                          // exactly one lane
-#pragma unroll
-                for (int j = 3; j >= 0; --j) {
-                    if (above + c[j] >= krem) { w_pt[0] = 4 * lane + j; w_pt[1] = krem - above; break; }
-                    above += c[j];
-                }
-            }
-        }
-        __syncthreads();
-        prefix |= (unsigned)w_pt[0] << shift;
-        pmask |= 255u << shift;
-        krem = w_pt[1];
-    }
-    if (!have_k) __syncthreads();                                        // publishes e_sc / e_id
-    if (have_k) {
-        const unsigned u = (prefix & 0x80000000u) ? (prefix & 0x7fffffffu) : ~prefix;
-        const float a_k = __uint_as_float(u);
+    // a_k = the k-th largest scan score (radix_select_kth: only the VALUE is needed -- every entry >= tau = a_k - 2 eps is re-scored,
+    // the k best among them; the first version found the k best one by one, k rounds of a block-wide arg-max with two barriers
+    // each: 40 % of this kernel)
+    {
+        const float a_k = radix_select_kth(e_sc, NE, p.k, hist, w_pt);
         if (a_k > -INFINITY) tau = a_k - two_eps;                        // (fewer than k listed rows: tau stays -inf, all of them go on)
     }
+    // sharded search: no row whose score is below (the best lower bound any shard has of the exact k-th best) - eps can be in the
+    // GLOBAL top-k, whatever this shard's own k-th best is -- the re-rank takes only what can still matter
+    if (cert && p.global_lb) tau = fmaxf(tau, p.global_lb[q] - 0.5f * two_eps);
     // everything >= tau goes on to the re-score; the used-up test: a FULL list whose last (= smallest) entry is >= tau
     int cnt = 0, used_up = 0;
     for (int i = tid; i < NE; i += RF_THREADS) cnt += (e_id[i] != IDX_SENTINEL && e_sc[i] >= tau) ? 1 : 0;
-    for (int l = tid; l < p.n_parts; l += RF_THREADS) {
-        const int last = l * p.part_len + p.part_len - 1;
-        if (e_id[last] != IDX_SENTINEL && e_sc[last] >= tau) used_up = 1;
-    }
+    if (p.part_cnt) used_up = filled > p.part_len ? 1 : 0;             // the scan emitted more than the buffer holds
+    else
+        for (int l = tid; l < p.n_parts; l += RF_THREADS) {
+            const int last = l * p.part_len + p.part_len - 1;
+            if (e_id[last] != IDX_SENTINEL && e_sc[last] >= tau) used_up = 1;
+        }
     int incl = cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -1134,6 +1182,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
         ++nsel;
         if (cert && nsel == p.k) tau = bs - two_eps;
     }
+    if (cert && p.global_lb && nsel == p.k) tau = fmaxf(tau, p.global_lb[q] - 0.5f * two_eps);     // (sharded search: see the staged form)
     if (cert) {
         int cnt = 0, used_up = 0;
         int endp[RF_MAXL];
@@ -1184,7 +1233,9 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     }
   }
     if (cert) {
-        if (floor_q > -INFINITY && !(nsel >= p.k && floor_q <= tau)) why |= 4;      // rows below the floor are unlisted
+        // rows below the floor are unlisted: the floor must not exceed tau (tau = -inf when fewer than k rows are listed, unless a
+        // global bound set it)
+        if (floor_q > -INFINITY && !(floor_q <= tau)) why |= 4;
         if (dropped_q) why |= 8;
         if (tid == 0) {
             if (why) p.flag_sel[atomicAdd(p.flag_count, 1)] = (int)q;
@@ -1747,6 +1798,16 @@ static int merge_lists(int metric, const KeyT* in_key, const int64_t* in_idx, in
     return RADAD_OK;
 }
 
+// what phase 2 of a search needs from phase 1 (knn_search_phase1 / _phase2 below)
+struct SearchCtx {
+    bool valid = false;
+    int64_t nq = 0;
+    int k = 0, l2 = 0, cslot = 0, n_parts = 0, plen = 0, cap = 0, xgroup = 1;
+    bool cert = false, emit = false, use_floor = false;
+    const float* q_use = nullptr;       // fp32 queries as the re-rank reads them (caller's buffer, or the workspace's normalised copy)
+    size_t o_eps = 0, o_thr = 0, o_cnt = 0, o_fcount = 0, o_fsel = 0, o_ps = 0, o_pi = 0, o_xk = 0, o_xi = 0;
+};
+
 // ---- handle -------------------------------------------------------------------------------------------
 struct radad_knn_s {
     int dim = 0, metric = 0, device = 0;
@@ -1787,7 +1848,9 @@ struct radad_knn_s {
     size_t ws_bytes = 0;
     int last_qtiles = 0, last_splits = 0, last_threads = KNN_THREADS;
     int last_kind = RADAD_SCAN_F32_TILE;   // which scan kernel the last search ran (radad_knn_last_scan_kind)
+    int last_scan_launches = 1;            // ... in how many launches
     EventRing prof;
+    SearchCtx pending;           // radad_knn_search_begin without its _finish yet
     std::mutex mu;
 };
 
@@ -2147,6 +2210,11 @@ int radad_knn_search_ex(radad_knn_t h, const void* q_dev, int q_dtype, int64_t n
 
 }  // extern "C"
 
+__global__ __launch_bounds__(256) void k_fill_f32(float* __restrict__ out, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
 // bf16 -> fp32 (exact): queries handed over as bfloat16 (BASELINE config 5) are decoded once, then take the fp32 path
 __global__ __launch_bounds__(256) void k_bf16_to_f32(const unsigned short* __restrict__ in, float* __restrict__ out, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -2163,23 +2231,21 @@ static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 // searches; the IVF coarse quantiser asks for fewer so that nprobe = 32 still fits the 32-entry register lists).
 //
 // Scan (a filter), one of:
-//   certified f16 scan (knn_hi.inc)   batches > 16 queries on stores with >= 64 tiles: hi plane of an fp32 store or the
-//                                     fp16 store itself, 16-entry lists per chunk whatever k is (k <= 128)
-//   k_knn_f32_smallq                  <= 16 queries, fp32 store: HBM-bound streaming
+//   certified f16 tile scan (knn_hi.inc)   batches > 16 queries (or small batches too wide for the streaming kernel's LDS) on
+//                                     stores of >= 16384 rows, k <= 128: hi plane of an fp32 store or the fp16 store itself; emits
+//                                     every row at or above the query's admission floor into the query's candidate buffer
+//   k_knn_hi_smallq / k_knn_f32_smallq     <= 16 queries: HBM-bound streaming of the f16 plane / the fp32 rows
 //   k_knn_f32_reg / k_knn_f32         the fp32 (or fp16-operand) tile kernels, lists of k + margin
 // then k_merge_refine: float64 re-rank of every candidate within 2 eps of the k-th, per-query certificate; then the
 // exact float64 kernel for the queries the certificate rejected (device-driven, usually zero work).  Nothing in here
 // synchronises with the host unless the workspace has to grow.
-static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t nq, int k, int margin, float* out_dist_dev,
-                           int64_t* out_idx_dev, double* out_key_dev, void* stream) {
-    RADAD_REQUIRE(h, "NULL handle");
-    RADAD_REQUIRE(k >= 1 && k <= RADAD_KNN_MAX_K, "radad_knn_search: k=%d outside [1,%d]", k, RADAD_KNN_MAX_K);
-    RADAD_REQUIRE(nq >= 0 && nq < (1ll << 31) - KT_N, "radad_knn_search: bad nq");
-    if (nq == 0) return RADAD_OK;
-    RADAD_REQUIRE(q_in && out_dist_dev && out_idx_dev, "radad_knn_search: NULL buffer");
-    std::lock_guard<std::mutex> lk(h->mu);
-    DeviceGuard g(h->device);
-    hipStream_t st = (hipStream_t)stream;
+//
+// Two halves around an optional exchange (radad_knn_search_begin / _finish, for row-sharded stores): phase 1 prepares the queries
+// and scans, and can report per query a lower bound of the exact k-th best score of THIS store; phase 2 re-ranks -- with the
+// maximum of the shards' bounds, only what can still be among the global k best -- and runs the exact kernel.
+
+static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64_t nq, int k, int margin, float* lb_out, hipStream_t st,
+                             SearchCtx* ctx) {
     // one workspace per handle: a search on another stream waits for the previous one (threads are serialised by h->mu,
     // the device work by this event)
     if (h->done_recorded) RADAD_HIP_CHECK(hipStreamWaitEvent(st, h->ev_done, 0));
@@ -2213,19 +2279,19 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     const size_t sq_lds_f32 = sizeof(float) * (size_t)nq * (h->dim + 4) + sq_slot_bytes;
     const bool sq_fits = nq <= SQ_NQ && ksel <= 32 &&
                          ((!h->hi_off && h->dim % 64 == 0 && sq_lds_hi <= SQ_LDS_BUDGET) || (!h->f16 && h->dim % 32 == 0 && sq_lds_f32 <= SQ_LDS_BUDGET));
-    // (k + margin <= 32: the admission floor is the (k + margin)-th best score of the sample; a lower floor would admit
-    // more than the 8 slots per query and tile can take)
-    if (cert && (nq >= wide_min_q || !sq_fits) && k + margin <= 32 && h->ntotal > 0 && h->dim % 64 == 0 && !h->hi_off) {
+    // the certified tile scan: any k the certificate covers (its candidate buffers are sized from k); the floor's rank k + margin
+    // must exist in the sample (16 entries per sample tile)
+    if (cert && (nq >= wide_min_q || !sq_fits) && h->ntotal > 0 && h->dim % 64 == 0 && !h->hi_off) {
         int wq, ws; int64_t wc;
         knn_geometry_wide(h->ntotal, nq, &wq, &ws, &wc);
-        // the threshold pre-pass: one tile per workgroup, at most KW_SAMPLE_SPLITS tiles, 1/8 of the store and
-        // KW_SAMPLE_BLOCKS workgroups; the certified scan needs it (its first tile would overflow the slots otherwise)
+        // the sample pre-pass: one tile per workgroup, at most KW_SAMPLE_SPLITS tiles, 1/8 of the store and KW_SAMPLE_BLOCKS
+        // workgroups
         s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
         s_splits = std::min(s_splits, std::max(8, (KW_SAMPLE_BLOCKS / wq) / 8 * 8));
         static_assert(KW_SAMPLE_SPLITS * 8 <= 64 * THR_LISTS_PER_LANE, "k_thr_from_parts: lists per lane");
-        if (s_splits >= 8) {
+        if (s_splits >= 8 && s_splits * KW_SAMPLE_LIST >= 2 * ksel) {
             if (h->hi_skip > 0) { --h->hi_skip; skipped_hi = true; }
-            else if (knn_ensure_hi(h, st, true)) { use_hi = true; n_qtiles = wq; n_splits = ws; chunk_rows = wc; }
+            else if (knn_ensure_hi(h, st, true)) { use_hi = true; n_qtiles = wq; }
         }
     }
     if (!use_hi && cert && !knn_ensure_hi(h, st, false)) { radad_set_error("store statistics could not be computed"); return RADAD_EHIP; }
@@ -2255,23 +2321,30 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         n_qtiles = 1;
     }
     const bool f16_tile = !use_hi && !smallq_hi && h->f16 && ksel <= 32 && h->dim % 64 == 0;
+    // the tile scan's phases: stores of more than 512 tiles are scanned in two launches -- the first eighth with the sample's floor,
+    // the rest with the floor the first eighth's candidates give (k_kth_floor) -- each launch a full round of workgroups
+    const int64_t hi_tiles = ceil_div64(std::max<int64_t>(h->ntotal, 1), KW_M);
+    const int64_t rows_a = (use_hi && hi_tiles > 512) ? ceil_div64(hi_tiles, 8) * KW_M : h->ntotal;
+    // candidate buffer of a query: the sample's floor admits ~8 (k + margin) rows of phase A (|A| <= 8 x the sample), the second floor
+    // ~k per remaining eighth: 32 (k + margin) leaves a factor of two; more (near-duplicate stores) rejects the query
+    const int emit_cap = use_hi ? std::min(RF_STAGE_MAX, std::max(1024, 32 * ksel)) : 0;
     h->last_qtiles = n_qtiles;
     h->last_threads = use_hi ? KW_THREADS : ((smallq || smallq_hi) ? SQ_THREADS : KNN_THREADS);
     h->last_kind = use_hi ? RADAD_SCAN_HI_TILE : smallq_hi ? RADAD_SCAN_HI_SMALLQ : smallq ? RADAD_SCAN_F32_SMALLQ
                           : f16_tile ? RADAD_SCAN_F16_TILE : RADAD_SCAN_F32_TILE;
-    h->last_splits = n_splits;
-    const int plen = use_hi ? KW_LIST : ksel;    // entries of a partial list
+    const int plen = use_hi ? emit_cap : ksel;   // entries of a partial list / of the candidate buffer
+    const int n_parts = use_hi ? 1 : n_splits;
     const int cap = cert ? std::max(k + KNN_CERT_EXTRA, KNN_CERT_CAP) : ksel;
     const int xgroup = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(64 * 1024) / ((size_t)h->dim * 4)));
 
-    // ---- workspace: qf (decoded bf16) | qn (normalised) | qh (f16 queries) | qscale | eps | thr_init | qflag |
+    // ---- workspace: qf (decoded bf16) | qn (normalised) | qh (f16 queries) | qscale | qconst | eps | thr_init | cand_cnt |
     //                 flag_count, flag_sel | part_score | part_idx | exact partial keys | ids
     const size_t qrow_f32 = al256((size_t)nq * h->dim * sizeof(float));
     const size_t b_qf = q_dtype == RADAD_Q_BF16 ? qrow_f32 : 0;
     const size_t b_qn = h->metric == RADAD_METRIC_COSINE ? qrow_f32 : 0;
     const size_t b_qh = (use_hi || f16_tile || smallq_hi) ? al256((size_t)nq * h->dim * 2) : 0;
     const size_t b_vec = al256((size_t)nq * sizeof(float));
-    const size_t part_elems = (size_t)nq * std::max<size_t>((size_t)n_splits * plen, use_hi ? (size_t)KW_SAMPLE_SPLITS * 16 : 0);
+    const size_t part_elems = (size_t)nq * std::max<size_t>((size_t)n_parts * plen, use_hi ? (size_t)KW_SAMPLE_SPLITS * KW_SAMPLE_LIST : 0);
     const size_t b_part = al256(part_elems * sizeof(float));
     const size_t b_xk = cert ? al256((size_t)nq * KX_SLICES * k * sizeof(double)) : 0;
     const size_t b_xi = cert ? al256((size_t)nq * KX_SLICES * k * sizeof(int)) : 0;
@@ -2283,8 +2356,8 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     const size_t o_qconst = off; off += b_vec;
     const size_t o_eps = off; off += b_vec;
     const size_t o_thr = off; off += b_vec;
-    const size_t o_qflag = off; off += b_vec;          // qflag [nq] int
-    const size_t o_fcount = off; off += 256;           // flag_count (same memset as qflag: contiguous)
+    const size_t o_cnt = off; off += b_vec;            // cand_cnt [nq] int (zeroed by k_hi_rows with the counters)
+    const size_t o_fcount = off; off += 256;           // flag_count + statistics
     const size_t o_fsel = off; off += b_vec;
     const size_t o_ps = off; off += b_part;
     const size_t o_pi = off; off += b_part;
@@ -2301,9 +2374,8 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     float* qconst = (float*)(ws + o_qconst);
     float* eps = (float*)(ws + o_eps);
     float* thr_init = (float*)(ws + o_thr);
-    int* qflag = (int*)(ws + o_qflag);
+    int* cand_cnt = (int*)(ws + o_cnt);
     int* flag_count = (int*)(ws + o_fcount);
-    int* flag_sel = (int*)(ws + o_fsel);
     float* ps = (float*)(ws + o_ps);
     int* pi = (int*)(ws + o_pi);
 
@@ -2336,7 +2408,7 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         hp.fixed_e = hi_q ? HI_E_PER_ROW : 0;            // the fp16 tile kernel multiplies un-scaled fp16 queries
         hp.l2 = l2; hp.exact_ops = (hi_q || f16_tile) ? 0 : 1;
         hp.norm_out = h->metric == RADAD_METRIC_COSINE ? (float*)(ws + o_qn) : nullptr;
-        hp.zero_flags = cert ? qflag : nullptr; hp.zero_counters = cert ? flag_count : nullptr;
+        hp.zero_flags = cert ? cand_cnt : nullptr; hp.zero_counters = cert ? flag_count : nullptr;
         hp.mu = mu; hp.mu_norm = mu ? h->mu_norm : 0.f; hp.biased = (biased || (f16_tile && l2)) ? 1 : 0;
         hp.bias_out = nullptr; hp.qconst_out = biased ? qconst : nullptr;
         hipLaunchKernelGGL(k_hi_rows, dim3(rgrid), dim3(256), 0, st, hp);
@@ -2359,9 +2431,10 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         // bias of the scale + bias variant: a centred plane has its own (|y - mu|^2 or mu.y); un-centred L2 uses |y|^2 as stored
         wp.rbias = mu ? h->rbias : h->ynorm; wp.bias_sign = l2 ? -1.f : 1.f; wp.mult = l2 ? 2.f : 1.f; wp.qconst = biased ? qconst : nullptr;
         wp.q = qh; wp.qscale = qscale;
-        wp.n = h->ntotal; wp.nq = (int)nq; wp.row_bytes = h->dim * 2; wp.l2 = l2;
-        wp.n_qtiles = n_qtiles; wp.n_splits = n_splits; wp.chunk_rows = chunk_rows; wp.part_score = ps; wp.part_idx = pi;
-        wp.thr_init = nullptr; wp.qflag = qflag;
+        wp.n = h->ntotal; wp.nq = (int)nq; wp.row_bytes = h->dim * 2; wp.l2 = l2; wp.id_off = 0;
+        wp.n_qtiles = n_qtiles; wp.part_score = ps; wp.part_idx = pi;
+        wp.cand_cap = emit_cap; wp.cand_cnt = cand_cnt;
+        wp.thr_init = nullptr;
         wp.debug = 0; wp.stamps = nullptr;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (make exp); never in the shipped library
         { const char* dbg = getenv("RADAD_DEBUG_KNN"); wp.debug = dbg ? atoi(dbg) : 0; }
@@ -2382,9 +2455,9 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
                                reinterpret_cast<const void*>(k_knn_hi_sample<2>)};
         RADAD_HIP_CHECK(hipFuncSetAttribute(fns[rsc], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RADAD_HIP_CHECK(hipFuncSetAttribute(sfns[rsc], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        // sample pre-pass: the 16th best score over the first rows of the store is a score at least 16 rows reach, so the
-        // full scan may admit from it instead of -inf (the score of a (row, query) pair does not depend on the tiling).
-        // It reuses the head of the partial arrays; the full scan overwrites them afterwards.
+        // sample pre-pass: the (k + margin)-th best score over the first rows of the store is a score at least k rows reach, so the
+        // scan admits from it (minus 2 eps) instead of -inf (the score of a (row, query) pair does not depend on the tiling).
+        // It uses the head of the candidate arrays; the scan overwrites them afterwards.
         {
             KnnHiParams sp = wp;
             sp.n = (int64_t)s_splits * KW_M; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
@@ -2397,11 +2470,33 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
             wp.thr_init = thr_init;
         }
         const dim3 b(KW_THREADS);
-        h->prof.begin(st);          // the event pair brackets the full-scan launch only (the kernel the roofline is quoted on)
-        if (rsc == 0) hipLaunchKernelGGL(k_knn_hi<0>, grid, b, lds, st, wp);
-        else if (rsc == 1) hipLaunchKernelGGL(k_knn_hi<1>, grid, b, lds, st, wp);
-        else hipLaunchKernelGGL(k_knn_hi<2>, grid, b, lds, st, wp);
-        h->prof.end(st);
+        auto launch_range = [&](int64_t r0, int64_t r1) {      // rows [r0, r1) of the store, one full round (or two) of workgroups
+            KnnHiParams rp = wp;
+            const size_t rb = (size_t)wp.row_bytes;
+            rp.db = (const char*)wp.db + (size_t)r0 * rb;
+            rp.rscale = wp.rscale ? wp.rscale + r0 : nullptr;
+            rp.rbias = wp.rbias ? wp.rbias + r0 : nullptr;
+            rp.n = r1 - r0; rp.id_off = r0;
+            int gq, gs; int64_t gc;
+            knn_geometry_wide(rp.n, nq, &gq, &gs, &gc);
+            rp.n_splits = gs; rp.chunk_rows = gc;
+            h->last_splits = gs;
+            const dim3 g2((unsigned)(gq * gs));
+            h->prof.begin(st);      // the event pair brackets a scan launch only (the kernel the roofline is quoted on; the phases of one
+                                    // search are two entries)
+            if (rsc == 0) hipLaunchKernelGGL(k_knn_hi<0>, g2, b, lds, st, rp);
+            else if (rsc == 1) hipLaunchKernelGGL(k_knn_hi<1>, g2, b, lds, st, rp);
+            else hipLaunchKernelGGL(k_knn_hi<2>, g2, b, lds, st, rp);
+            h->prof.end(st);
+        };
+        h->last_scan_launches = rows_a < h->ntotal ? 2 : 1;
+        launch_range(0, rows_a);
+        if (rows_a < h->ntotal) {
+            KthParams kp;
+            kp.score = ps; kp.cnt = cand_cnt; kp.cap = emit_cap; kp.k = k; kp.eps = eps; kp.floor_io = thr_init; kp.lb_out = nullptr;
+            hipLaunchKernelGGL(k_kth_floor, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)emit_cap * 4 + 1040, st, kp);
+            launch_range(rows_a, h->ntotal);
+        }
 #ifdef RADAD_DEBUG_HOOKS
         if (wp.stamps) {
             std::vector<unsigned long long> hs(8 * 4096);
@@ -2476,56 +2571,137 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
         else hipLaunchKernelGGL(k_knn_f32<false>, grid, dim3(KNN_THREADS), knn_lds_bytes(), st, p);
         h->prof.end(st);
     }
+    if (!use_hi) { h->last_splits = n_splits; h->last_scan_launches = 1; }
     RADAD_HIP_CHECK(hipGetLastError());
 
+    // ---- sharded search: a lower bound of the exact k-th best score of this store, per query ------------------------------
+    // a_k - eps with a_k the k-th best scan score (the k rows with the best scan scores have exact scores >= that).  The scan
+    // score of the tile / streaming f16 kernels estimates q.y (inner product, cosine) or -|q - y|^2 (L2) whatever the plane's
+    // centring, so the bounds of different shards compare; the other kernels report no bound (-inf).
+    if (lb_out) {
+        if (use_hi && cert) {
+            KthParams kp;
+            kp.score = ps; kp.cnt = cand_cnt; kp.cap = emit_cap; kp.k = k; kp.eps = eps; kp.floor_io = nullptr; kp.lb_out = lb_out;
+            hipLaunchKernelGGL(k_kth_floor, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)emit_cap * 4 + 1040, st, kp);
+        } else {
+            hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, st, lb_out, nq, -INFINITY);
+        }
+        RADAD_HIP_CHECK(hipGetLastError());
+    }
+
+    ctx->valid = true;
+    ctx->nq = nq; ctx->k = k; ctx->l2 = l2; ctx->cslot = cslot; ctx->n_parts = n_parts; ctx->plen = plen; ctx->cap = cap; ctx->xgroup = xgroup;
+    ctx->cert = cert; ctx->emit = use_hi; ctx->use_floor = use_hi; ctx->q_use = q_use;
+    ctx->o_eps = o_eps; ctx->o_thr = o_thr; ctx->o_cnt = o_cnt; ctx->o_fcount = o_fcount; ctx->o_fsel = o_fsel; ctx->o_ps = o_ps; ctx->o_pi = o_pi;
+    ctx->o_xk = o_xk; ctx->o_xi = o_xi;
+    return RADAD_OK;
+}
+
+static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* global_lb, float* out_dist_dev, int64_t* out_idx_dev,
+                             double* out_key_dev, hipStream_t st) {
+    char* ws = (char*)h->ws;
+    int* flag_count = (int*)(ws + c.o_fcount);
+    int* flag_sel = (int*)(ws + c.o_fsel);
+    const int64_t nq = c.nq;
+    const int k = c.k;
     // ---- float64 re-rank + certificate ----------------------------------------------------------------------------
     RefineParams m;
-    m.score = ps; m.idx = pi; m.n_parts = n_splits; m.k = k; m.dim = h->dim; m.l2 = l2; m.nq = nq;
-    m.part_len = plen; m.cap = cap;
-    m.eps = cert ? eps : nullptr; m.thr_init = use_hi ? thr_init : nullptr; m.qflag = (cert && use_hi) ? qflag : nullptr;
+    m.score = (const float*)(ws + c.o_ps); m.idx = (const int*)(ws + c.o_pi); m.n_parts = c.n_parts; m.k = k; m.dim = h->dim; m.l2 = c.l2; m.nq = nq;
+    m.part_len = c.plen; m.cap = c.cap;
+    m.eps = c.cert ? (const float*)(ws + c.o_eps) : nullptr; m.thr_init = c.use_floor ? (const float*)(ws + c.o_thr) : nullptr; m.qflag = nullptr;
+    m.part_cnt = c.emit ? (const int*)(ws + c.o_cnt) : nullptr; m.global_lb = c.cert ? global_lb : nullptr;
     m.flag_count = flag_count; m.flag_sel = flag_sel;
-    m.db = h->rows; m.db_f16 = h->f16; m.q = q_use; m.id_map = nullptr; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
+    m.db = h->rows; m.db_f16 = h->f16; m.q = c.q_use; m.id_map = nullptr; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
     m.out_key = out_key_dev;
     m.debug = 0;
 #ifdef RADAD_DEBUG_HOOKS
     { const char* dbg = getenv("RADAD_DEBUG_KNN"); m.debug = dbg ? atoi(dbg) : 0; }
 #endif
-    m.stats = cert ? flag_count + 1 : nullptr;
-    RADAD_REQUIRE(n_splits <= RF_THREADS * RF_MAXL, "radad_knn_search: %d partial lists per query exceed the re-rank kernel's %d", n_splits,
+    m.stats = c.cert ? flag_count + 1 : nullptr;
+    RADAD_REQUIRE(c.n_parts <= RF_THREADS * RF_MAXL, "radad_knn_search: %d partial lists per query exceed the re-rank kernel's %d", c.n_parts,
                   RF_THREADS * RF_MAXL);
     {   // certified mode with lists that fit the LDS: selection on a staged copy (one round of loads instead of a pointer chase)
         const size_t entries = (size_t)m.n_parts * m.part_len;
+        RADAD_REQUIRE(!c.emit || (m.eps && entries <= (size_t)RF_STAGE_MAX), "radad_knn_search: candidate buffer larger than the re-rank stages");
         if (m.eps && entries <= (size_t)RF_STAGE_MAX)
-            hipLaunchKernelGGL(k_merge_refine<true>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(cap) + entries * 8 + 1024, st, m);
+            hipLaunchKernelGGL(k_merge_refine<true>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(c.cap) + entries * 8 + 1024, st, m);
         else
-            hipLaunchKernelGGL(k_merge_refine<false>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(cap), st, m);
+            hipLaunchKernelGGL(k_merge_refine<false>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(c.cap), st, m);
     }
     RADAD_HIP_CHECK(hipGetLastError());
 
     // ---- the queries the certificate rejected: exact float64 search, sized and driven by the device-side count ------
-    if (cert) {
+    if (c.cert) {
         ExactParams x;
-        x.db = h->rows; x.db_f16 = h->f16; x.q = q_use; x.sel = flag_sel; x.count = flag_count;
-        x.n = h->ntotal; x.dim = h->dim; x.k = k; x.l2 = l2; x.group = xgroup;
+        x.db = h->rows; x.db_f16 = h->f16; x.q = c.q_use; x.sel = flag_sel; x.count = flag_count;
+        x.n = h->ntotal; x.dim = h->dim; x.k = k; x.l2 = c.l2; x.group = c.xgroup;
         x.slice_rows = ceil_div64(std::max<int64_t>(h->ntotal, 1), KX_SLICES);
-        x.pkey = (double*)(ws + o_xk); x.pidx = (int*)(ws + o_xi); x.id_base = h->id_base;
+        x.pkey = (double*)(ws + c.o_xk); x.pidx = (int*)(ws + c.o_xi); x.id_base = h->id_base;
         x.out_dist = out_dist_dev; x.out_idx = out_idx_dev; x.out_key = out_key_dev;
-        x.host_stats = h->host_count_dev + 8 * cslot;
-        const size_t xlds = (size_t)xgroup * h->dim * 4 + (size_t)KX_WAVES * xgroup * k * 12 + 16;
+        x.host_stats = h->host_count_dev + 8 * c.cslot;
+        const size_t xlds = (size_t)c.xgroup * h->dim * 4 + (size_t)KX_WAVES * c.xgroup * k * 12 + 16;
         RADAD_REQUIRE(xlds <= 160 * 1024, "radad_knn_search: dim %d x k %d too large for the exact kernel", h->dim, k);
         RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_exact_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
         hipLaunchKernelGGL(k_exact_scan, dim3(KX_SLICES, KX_GROUPS_Y), dim3(KX_THREADS), xlds, st, x);
         hipLaunchKernelGGL(k_exact_merge, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, x);
         RADAD_HIP_CHECK(hipGetLastError());
-        RADAD_HIP_CHECK(hipEventRecord(h->ev_count[cslot], st));      // (k_exact_merge has written the counters to the pinned host copy)
-        h->count_pending[cslot] = true;
-        h->count_nq[cslot] = nq;
+        RADAD_HIP_CHECK(hipEventRecord(h->ev_count[c.cslot], st));      // (k_exact_merge has written the counters to the pinned host copy)
+        h->count_pending[c.cslot] = true;
+        h->count_nq[c.cslot] = nq;
         ++h->search_seq;
     }
     RADAD_HIP_CHECK(hipEventRecord(h->ev_done, st));
     h->done_recorded = true;
     return RADAD_OK;
 }
+
+static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t nq, int k, int margin, float* out_dist_dev,
+                           int64_t* out_idx_dev, double* out_key_dev, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    RADAD_REQUIRE(k >= 1 && k <= RADAD_KNN_MAX_K, "radad_knn_search: k=%d outside [1,%d]", k, RADAD_KNN_MAX_K);
+    RADAD_REQUIRE(nq >= 0 && nq < (1ll << 31) - KT_N, "radad_knn_search: bad nq");
+    if (nq == 0) return RADAD_OK;
+    RADAD_REQUIRE(q_in && out_dist_dev && out_idx_dev, "radad_knn_search: NULL buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    RADAD_REQUIRE(!h->pending.valid, "radad_knn_search: a radad_knn_search_begin on this handle has not been finished");
+    SearchCtx c;
+    int rc = knn_search_phase1(h, q_in, q_dtype, nq, k, margin, nullptr, (hipStream_t)stream, &c);
+    if (rc) return rc;
+    return knn_search_phase2(h, c, nullptr, out_dist_dev, out_idx_dev, out_key_dev, (hipStream_t)stream);
+}
+
+extern "C" {
+
+int radad_knn_search_begin(radad_knn_t h, const void* q_dev, int q_dtype, int64_t nq, int k, float* kth_lower_bound_dev, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    RADAD_REQUIRE(q_dtype == RADAD_Q_F32 || q_dtype == RADAD_Q_BF16, "radad_knn_search_begin: unsupported query dtype %d", q_dtype);
+    RADAD_REQUIRE(k >= 1 && k <= RADAD_KNN_MAX_K, "radad_knn_search_begin: k=%d outside [1,%d]", k, RADAD_KNN_MAX_K);
+    RADAD_REQUIRE(nq > 0 && nq < (1ll << 31) - KT_N, "radad_knn_search_begin: bad nq");
+    RADAD_REQUIRE(q_dev && kth_lower_bound_dev, "radad_knn_search_begin: NULL buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    RADAD_REQUIRE(!h->pending.valid, "radad_knn_search_begin: the previous begin on this handle has not been finished");
+    SearchCtx c;
+    int rc = knn_search_phase1(h, q_dev, q_dtype, nq, k, KNN_MARGIN, kth_lower_bound_dev, (hipStream_t)stream, &c);
+    if (rc) return rc;
+    h->pending = c;
+    return RADAD_OK;
+}
+
+int radad_knn_search_finish(radad_knn_t h, const float* global_lower_bound_dev, float* out_dist_dev, int64_t* out_idx_dev,
+                            double* out_key_dev, void* stream) {
+    RADAD_REQUIRE(h, "NULL handle");
+    RADAD_REQUIRE(out_dist_dev && out_idx_dev, "radad_knn_search_finish: NULL buffer");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    RADAD_REQUIRE(h->pending.valid, "radad_knn_search_finish: no search was begun on this handle");
+    const SearchCtx c = h->pending;
+    h->pending.valid = false;
+    return knn_search_phase2(h, c, global_lower_bound_dev, out_dist_dev, out_idx_dev, out_key_dev, (hipStream_t)stream);
+}
+
+}  // extern "C"
 
 extern "C" {
 
@@ -2639,6 +2815,12 @@ int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, i
     if (n_query_tiles) *n_query_tiles = h->last_qtiles;
     if (n_db_splits) *n_db_splits = h->last_splits;
     if (block_threads) *block_threads = h->last_threads;
+    return RADAD_OK;
+}
+
+int radad_knn_last_scan_launches(radad_knn_t h, int* n_launches) {
+    RADAD_REQUIRE(h && n_launches, "NULL argument");
+    *n_launches = h->last_scan_launches;
     return RADAD_OK;
 }
 

@@ -157,6 +157,44 @@ class HipFlatIndex:
                                                      _lib.stream_ptr(q.device)), "radad_knn_search")
         return (D, I, K64) if return_f64 else (D, I)
 
+    def search_begin(self, q, k: int):
+        """first half of a search over a row shard (sharded.py): prepares the queries and scans this shard; returns a float32 CUDA
+        tensor [nq] -- per query a lower bound of the exact k-th best score of THIS shard (q.y / -|q - y|^2; -inf when none).
+        The caller all-reduces (max) it over the shards and passes the result to search_finish."""
+        import torch
+        _lib.require_cuda(q, "q")
+        bf16 = q.dtype == torch.bfloat16
+        q = q.contiguous() if bf16 else q.contiguous().float()
+        if q.dim() != 2 or q.shape[1] != self.d:
+            raise ValueError(f"search expects [nq, {self.d}], got {tuple(q.shape)}")
+        lb = torch.empty((q.shape[0],), device=q.device, dtype=torch.float32)
+        with torch.cuda.device(q.device):
+            _lib.check(self._lib.radad_knn_search_begin(self._h, q.data_ptr(), _lib.Q_BF16 if bf16 else _lib.Q_F32, q.shape[0], int(k),
+                                                        lb.data_ptr(), _lib.stream_ptr(q.device)), "radad_knn_search_begin")
+        self._begun = (q, int(k))          # (keeps the queries alive until the second half has read them)
+        return lb
+
+    def search_finish(self, global_lb=None, return_f64: bool = False):
+        """second half: float64 re-rank of what can still be among the GLOBAL k best (global_lb: the element-wise maximum of the
+        shards' search_begin bounds; None = this shard's own top k), then the exact kernel for uncertified queries.
+        -> (D, I[, K64]) as search_device; with a bound a row may hold fewer than k real entries (-1 filled)."""
+        import torch
+        q, k = self._begun
+        self._begun = None
+        D = torch.empty((q.shape[0], k), device=q.device, dtype=torch.float32)
+        I = torch.empty((q.shape[0], k), device=q.device, dtype=torch.int64)
+        K64 = torch.empty((q.shape[0], k), device=q.device, dtype=torch.float64) if return_f64 else None
+        if global_lb is not None:
+            _lib.require_cuda(global_lb, "global_lb")
+            global_lb = global_lb.contiguous().float()
+            if global_lb.numel() != q.shape[0]:
+                raise ValueError("global_lb must hold one bound per query")
+        with torch.cuda.device(q.device):
+            _lib.check(self._lib.radad_knn_search_finish(self._h, global_lb.data_ptr() if global_lb is not None else None, D.data_ptr(),
+                                                         I.data_ptr(), K64.data_ptr() if return_f64 else None,
+                                                         _lib.stream_ptr(q.device)), "radad_knn_search_finish")
+        return (D, I, K64) if return_f64 else (D, I)
+
     def reconstruct_batch(self, idx):
         """idx: int64 CUDA tensor of any shape -> [*idx.shape, d]; negative ids give zero rows."""
         import torch
@@ -173,9 +211,11 @@ class HipFlatIndex:
         _lib.check(self._lib.radad_knn_last_launch(self._h, C.byref(a), C.byref(b), C.byref(c)))
         st, nq = (C.c_int * 6)(), C.c_int64()
         _lib.check(self._lib.radad_knn_last_certificate(self._h, C.byref(nq), st))
-        kind = C.c_int()
+        kind, nl = C.c_int(), C.c_int()
         _lib.check(self._lib.radad_knn_last_scan_kind(self._h, C.byref(kind)))
+        _lib.check(self._lib.radad_knn_last_scan_launches(self._h, C.byref(nl)))
         return {"query_tiles": a.value, "db_splits": b.value, "block_threads": c.value, "rechecked_queries": st[0],
+                "scan_launches": nl.value,
                 "scan_kind": ("f32_tile", "hi_tile", "f32_smallq", "hi_smallq", "f16_tile")[kind.value],
                 "certificate": {"queries": nq.value, "rejected": st[0], "candidates_rescored": st[1],
                                 "rejected_buffer_full": st[2], "rejected_list_used_up": st[3],
