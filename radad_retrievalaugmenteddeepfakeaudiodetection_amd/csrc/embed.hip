@@ -593,7 +593,7 @@ __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__
         if (tid == 1023) s_carry = base + inc;
         __syncthreads();
     }
-    bad = __syncthreads_or(bad);
+    bad = (__syncthreads_or(bad & 1) ? 1 : 0) | (__syncthreads_or(bad & 2) ? 2 : 0);      // (a predicate per flag: the builtin ORs truth values)
     if (tid == 0) {
         clip_seg[n_clips] = s_carry < seg_cap ? s_carry : seg_cap;
         n_seg_out[0] = (int)(s_carry < seg_cap ? s_carry : seg_cap);

@@ -931,7 +931,6 @@ constexpr int KNN_CERT_EXTRA = 32;       // candidates beyond k the certified re
 constexpr int KNN_CERT_CAP = 512;        // ... and this many in all: stores of near-duplicates (the benchmark plants 2048 rows
                                          // within 2e-2 of every query) put hundreds of rows within 2 eps of the k-th
 constexpr int KNN_CERT_MAX_K = 128;      // largest k the certificate + exact kernel cover
-constexpr int KW_SAMPLE_BLOCKS = 1024;   // workgroups of the threshold pre-pass, at most (4 waves of one-tile workgroups)
 constexpr int KW_SAMPLE_SPLITS = 64;     // one-tile splits of the threshold pre-pass (<= 16384 rows)
 
 struct RefineParams {
@@ -1826,7 +1825,7 @@ struct radad_knn_s {
     int64_t stat_rows = 0;
     // centred plane (decided when the plane is built, from the rows the store holds then): the plane holds f16((y - mu) 2^e)
     float* cmu = nullptr;        // [dim] the common component, or nullptr: plane of the rows themselves
-    float mu_norm = 0.f;         // |mu|
+    float mu_norm = 0.f, mu_sq = 0.f;   // |mu| (rounded up: it enters error bounds) and |mu|^2 as summed on the device
     float* rbias = nullptr;      // [hi_cap] per-row bias of a centred plane: |y - mu|^2 (L2) or mu.y (IP / cosine)
     // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
     // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
@@ -1949,7 +1948,7 @@ static void knn_drop_plane(radad_knn_t h) {
     if (h->rscale) (void)hipFree(h->rscale);
     if (h->cmu) (void)hipFree(h->cmu);
     if (h->rbias) (void)hipFree(h->rbias);
-    h->hi = nullptr; h->rscale = nullptr; h->cmu = nullptr; h->rbias = nullptr; h->mu_norm = 0.f;
+    h->hi = nullptr; h->rscale = nullptr; h->cmu = nullptr; h->rbias = nullptr; h->mu_norm = 0.f; h->mu_sq = 0.f;
     h->hi_rows = 0; h->hi_cap = 0;
 }
 
@@ -1982,6 +1981,7 @@ static bool knn_choose_centre(radad_knn_t h, hipStream_t st) {
     if (!centre) { if (mu) (void)hipFree(mu); (void)hipGetLastError(); return false; }
     h->cmu = mu;
     h->mu_norm = sqrtf(host2[0]) * (1.0f + 0x1p-10f);
+    h->mu_sq = host2[0];
     return true;
 }
 
@@ -1989,8 +1989,8 @@ static bool knn_choose_centre(radad_knn_t h, hipStream_t st) {
 // (appends only touch the new rows).  Returns false when the plane was wanted but is not available.
 static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
     if (!h->stat) {
-        if (hipMalloc(&h->stat, 3 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
-        (void)hipMemsetAsync(h->stat, 0, 3 * sizeof(unsigned), st);
+        if (hipMalloc(&h->stat, 4 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        (void)hipMemsetAsync(h->stat, 0, 4 * sizeof(unsigned), st);
         h->stat_rows = 0;
     }
     const bool plane = want_plane && !h->hi_off && !h->f16 && h->dim % 64 == 0;
@@ -2009,7 +2009,7 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
             h->hi_cap = h->capacity;
         }
         // the statistics describe the operands of the plane (y - mu when centred): start them over with it
-        (void)hipMemsetAsync(h->stat, 0, 3 * sizeof(unsigned), st);
+        (void)hipMemsetAsync(h->stat, 0, 4 * sizeof(unsigned), st);
         h->stat_rows = 0;
     }
     const bool have_plane = plane && h->hi;
@@ -2027,7 +2027,7 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
         hp.fixed_e = h->f16 ? 0 : ((h->metric == RADAD_METRIC_COSINE && !h->cmu) ? 14 : HI_E_PER_ROW);
         hp.l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0; hp.exact_ops = h->f16 ? 1 : 0;
         // (a plane that exists keeps its centring for the statistics-only calls too: the statistics are those of ITS operands)
-        hp.mu = h->cmu; hp.mu_norm = h->mu_norm; hp.biased = 0;
+        hp.mu = h->cmu; hp.mu_norm = h->mu_norm; hp.mu_sq = h->mu_sq; hp.biased = 0;
         hp.bias_out = (have_plane && h->rbias) ? h->rbias + from : nullptr; hp.qconst_out = nullptr;
         hipLaunchKernelGGL(k_hi_rows, dim3((unsigned)ceil_div64(hp.n, 4)), dim3(256), 0, st, hp);
         if (hipGetLastError() != hipSuccess) return false;
@@ -2284,10 +2284,9 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     if (cert && (nq >= wide_min_q || !sq_fits) && h->ntotal > 0 && h->dim % 64 == 0 && !h->hi_off) {
         int wq, ws; int64_t wc;
         knn_geometry_wide(h->ntotal, nq, &wq, &ws, &wc);
-        // the sample pre-pass: one tile per workgroup, at most KW_SAMPLE_SPLITS tiles, 1/8 of the store and KW_SAMPLE_BLOCKS
-        // workgroups
+        // the sample pre-pass: one tile per workgroup, at most KW_SAMPLE_SPLITS tiles and 1/8 of the store (whatever the number of
+        // query tiles: every phase of the scan is sized from the sample, a small sample means more phases)
         s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
-        s_splits = std::min(s_splits, std::max(8, (KW_SAMPLE_BLOCKS / wq) / 8 * 8));
         static_assert(KW_SAMPLE_SPLITS * 8 <= 64 * THR_LISTS_PER_LANE, "k_thr_from_parts: lists per lane");
         if (s_splits >= 8 && s_splits * KW_SAMPLE_LIST >= 2 * ksel) {
             if (h->hi_skip > 0) { --h->hi_skip; skipped_hi = true; }
@@ -2321,12 +2320,11 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         n_qtiles = 1;
     }
     const bool f16_tile = !use_hi && !smallq_hi && h->f16 && ksel <= 32 && h->dim % 64 == 0;
-    // the tile scan's phases: stores of more than 512 tiles are scanned in two launches -- the first eighth with the sample's floor,
-    // the rest with the floor the first eighth's candidates give (k_kth_floor) -- each launch a full round of workgroups
-    const int64_t hi_tiles = ceil_div64(std::max<int64_t>(h->ntotal, 1), KW_M);
-    const int64_t rows_a = (use_hi && hi_tiles > 512) ? ceil_div64(hi_tiles, 8) * KW_M : h->ntotal;
-    // candidate buffer of a query: the sample's floor admits ~8 (k + margin) rows of phase A (|A| <= 8 x the sample), the second floor
-    // ~k per remaining eighth: 32 (k + margin) leaves a factor of two; more (near-duplicate stores) rejects the query
+    // the tile scan's phases: a floor taken from m rows admits ~(rank / m) of what it is applied to, so every launch covers at most
+    // 8 x the rows its floor was taken from -- the first 8 x the sample with the sample's floor, the next 8 x that with the floor the
+    // candidates so far give (k_kth_floor), and so on: 2 launches up to 1.2 M rows, 3 up to 9.5 M.  Each admits ~8 (k + margin) rows
+    // per query; the candidate buffer holds 32 (k + margin) (>= 1024): more (stores of near-duplicates) rejects the query.
+    const int64_t hi_phase0 = (int64_t)8 * s_splits * KW_M;
     const int emit_cap = use_hi ? std::min(RF_STAGE_MAX, std::max(1024, 32 * ksel)) : 0;
     h->last_qtiles = n_qtiles;
     h->last_threads = use_hi ? KW_THREADS : ((smallq || smallq_hi) ? SQ_THREADS : KNN_THREADS);
@@ -2409,7 +2407,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         hp.l2 = l2; hp.exact_ops = (hi_q || f16_tile) ? 0 : 1;
         hp.norm_out = h->metric == RADAD_METRIC_COSINE ? (float*)(ws + o_qn) : nullptr;
         hp.zero_flags = cert ? cand_cnt : nullptr; hp.zero_counters = cert ? flag_count : nullptr;
-        hp.mu = mu; hp.mu_norm = mu ? h->mu_norm : 0.f; hp.biased = (biased || (f16_tile && l2)) ? 1 : 0;
+        hp.mu = mu; hp.mu_norm = mu ? h->mu_norm : 0.f; hp.mu_sq = mu ? h->mu_sq : 0.f; hp.biased = (biased || (f16_tile && l2)) ? 1 : 0;
         hp.bias_out = nullptr; hp.qconst_out = biased ? qconst : nullptr;
         hipLaunchKernelGGL(k_hi_rows, dim3(rgrid), dim3(256), 0, st, hp);
     }
@@ -2489,13 +2487,21 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             else hipLaunchKernelGGL(k_knn_hi<2>, g2, b, lds, st, rp);
             h->prof.end(st);
         };
-        h->last_scan_launches = rows_a < h->ntotal ? 2 : 1;
-        launch_range(0, rows_a);
-        if (rows_a < h->ntotal) {
-            KthParams kp;
-            kp.score = ps; kp.cnt = cand_cnt; kp.cap = emit_cap; kp.k = k; kp.eps = eps; kp.floor_io = thr_init; kp.lb_out = nullptr;
-            hipLaunchKernelGGL(k_kth_floor, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)emit_cap * 4 + 1040, st, kp);
-            launch_range(rows_a, h->ntotal);
+        h->last_scan_launches = 0;
+        for (int64_t r0 = 0, span = hi_phase0; r0 < h->ntotal; span *= 8) {
+            // (a last phase of less than a quarter of its predecessor is not worth a launch of its own: it joins it)
+            int64_t r1 = std::min<int64_t>(h->ntotal, r0 + span);
+            if (h->ntotal - r1 < span / 4) r1 = h->ntotal;
+            // a store the sample's floor alone filters to a third of the buffer (~(k + margin) N / sample rows) is scanned in one go
+            if (r0 == 0 && (int64_t)ksel * h->ntotal <= (int64_t)(emit_cap / 3) * s_splits * KW_M) r1 = h->ntotal;
+            if (r0 > 0) {
+                KthParams kp;
+                kp.score = ps; kp.cnt = cand_cnt; kp.cap = emit_cap; kp.k = k; kp.eps = eps; kp.floor_io = thr_init; kp.lb_out = nullptr;
+                hipLaunchKernelGGL(k_kth_floor, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)emit_cap * 4 + 1040, st, kp);
+            }
+            launch_range(r0, r1);
+            ++h->last_scan_launches;
+            r0 = r1;
         }
 #ifdef RADAD_DEBUG_HOOKS
         if (wp.stamps) {
@@ -2926,7 +2932,7 @@ int snap_load_range(radad_knn_t h, const char* path, int64_t row0, int64_t n_row
     RADAD_HIP_CHECK(hipDeviceSynchronize());
     h->ntotal = 0;
     h->hi_rows = 0; h->stat_rows = 0;      // the hi plane and the statistics describe the old contents
-    if (h->stat) RADAD_HIP_CHECK(hipMemset(h->stat, 0, 3 * sizeof(unsigned)));
+    if (h->stat) RADAD_HIP_CHECK(hipMemset(h->stat, 0, 4 * sizeof(unsigned)));
     if ((rc = knn_grow(h, n_rows))) return rc;
     const unsigned char* src = map.base + hd.payload_off + (size_t)row0 * rb;
     const size_t total = (size_t)n_rows * rb;
