@@ -606,9 +606,12 @@ def test_large_k_stays_on_the_certified_f16_scan(gpu, metric, k):
     assert info["scan_kind"] == "hi_tile" and info["certificate"]["rejected"] <= nq // 100, info
     import torch
     stored = idx.reconstruct_batch(torch.arange(n, device=gpu)).cpu().numpy()
-    qq = q.astype(np.float64)
-    if metric == "COSINE":
-        qq = qq / np.sqrt((qq ** 2).sum(1))[:, None]
+    qq = q
+    if metric == "COSINE":        # the ranking is defined on the queries as the index normalises them (fp32, vector_database.py:166);
+        qt = torch.from_numpy(q).to(gpu); qo = torch.empty_like(qt)           # checked against float64 numpy to 1e-6
+        _lib.check(_lib.load().radad_rownorm(qt.data_ptr(), qo.data_ptr(), nq, dim, 0, _lib.stream_ptr(gpu)))
+        qq = qo.cpu().numpy()
+        np.testing.assert_allclose(qq, q.astype(np.float64) / np.sqrt((q.astype(np.float64) ** 2).sum(1))[:, None], rtol=0, atol=1e-6)
     od, oi = O.knn(stored, qq, k, "IP" if metric == "COSINE" else "L2")
     assert O.rank_gaps(od).min() > 0
     np.testing.assert_array_equal(I, oi)
