@@ -87,6 +87,8 @@ def main():
                     "(pinned host -> device, double-buffered on a copy stream, overlapped with the previous step); 0 = skip")
     ap.add_argument("--unstructured", type=int, default=10, help="searches of 1024 random (unstructured) queries timed after the "
                     "headline steps for the `scan_unstructured_ms` key (0 = skip)")
+    ap.add_argument("--shard-bound", type=int, default=1, help="N > 1: 1 = exchange per-query k-th-best bounds between scan and "
+                    "re-rank (default), 0 = every shard certifies its own top k")
     ap.add_argument("--mode", choices=["step", "predict"], default="step")
     ap.add_argument("--predict-queries", type=int, default=1)
     ap.add_argument("--dim", type=int, default=DIM, help="--mode predict only: embedding dimension of the store (the reference's own "
@@ -243,7 +245,15 @@ def main():
             return vdb.index.search_device(q, k)
         _, ids, key64 = vdb.index.search_device(q, k, return_f64=True)
         return key64, ids
-    searcher = ShardedSearch(local_search, vdb.index.metric)
+    # N > 1: the search runs in two halves around an all-reduce(max) of per-query bounds (sharded.py), so that every shard
+    # re-ranks only what can be among the GLOBAL top k
+    bounded = None
+    if world > 1 and args.shard_bound:
+        def _finish(lb):
+            _, ids, key64 = vdb.index.search_finish(lb, return_f64=True)
+            return key64, ids
+        bounded = (vdb.index.search_begin, _finish)
+    searcher = ShardedSearch(local_search, vdb.index.metric, bounded=bounded, timing=(world > 1 and not rehearse))
 
     def barrier():
         if world > 1:
@@ -315,6 +325,8 @@ def main():
     lm_ms, pp_ms = fe.profile_read()
     launch = vdb.index.last_launch()
     rechecked = launch["rechecked_queries"]
+    n_launch = max(1, launch.get("scan_launches", 1))       # the tile scan covers a large store in several launches: one entry each
+    shard_ms = searcher.timings() if world > 1 else []
 
     # ---- sustained: the same step, looped for >= args.sustain seconds (the chip settles at its steady-state clock) ------
     sustained = None
@@ -332,7 +344,7 @@ def main():
         k2 = vdb.index.profile_read()
         l2_, p2_ = fe.profile_read()
         sustained = {"seconds": round(el, 2), "steps": n_s, "value": round(world * B * n_s / el, 1), "unit": "clips/s",
-                     "ms_per_step": round(1e3 * el / n_s, 4), "scan_ms": round(float(np.mean(k2)), 4),
+                     "ms_per_step": round(1e3 * el / n_s, 4), "scan_ms": round(float(np.mean(k2)) * n_launch, 4),
                      "k_logmel_ms": round(float(np.mean(l2_)), 4), "k_proj_pool_ms": round(float(np.mean(p2_)), 4)}
     # ---- the same scan on UNSTRUCTURED queries (random directions against the same store: no planted rows near them, so the
     # sample-based admission floor is low and the epilogue's push / drain path works hardest -- what a store of unrelated
@@ -353,7 +365,7 @@ def main():
                 index.search_device(qu, TOP_K)
             ms_u = index.profile_read()
             la = index.last_launch()
-            scan_unstructured[name] = {"scan_ms": round(float(np.mean(ms_u)), 4), "scan_kind": la["scan_kind"],
+            scan_unstructured[name] = {"scan_ms": round(float(np.mean(ms_u)) * max(1, la.get("scan_launches", 1)), 4), "scan_kind": la["scan_kind"],
                                        "rejected": la["certificate"]["rejected"],
                                        "candidates_per_query": round(la["certificate"]["candidates_rescored"] / B, 1)}
             index.profile(False)
@@ -419,7 +431,10 @@ def main():
 
     ms_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
-    knn_avg = float(np.mean(knn_ms)) if knn_ms else float("nan")
+    # scan time of one search = its launches added up; the roofline is quoted per LAUNCH (average duration against average work),
+    # which is what `rocprofv3 --stats` averages too
+    knn_launch_avg = float(np.mean(knn_ms)) if knn_ms else float("nan")
+    knn_avg = knn_launch_avg * n_launch
     flops = 2.0 * Q * (hi - lo) * DIM                                   # algorithmic FLOPs of one scan launch
     f16 = args.store_dtype == "f16"
     esz = 2.0 if f16 else 4.0
@@ -473,7 +488,8 @@ def main():
         "roofline": {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 2),
                      "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel_ms": round(knn_avg, 4), "flops_per_launch": flops, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel_ms": round(knn_launch_avg, 4), "launches_per_step": n_launch, "scan_ms_per_step": round(knn_avg, 4),
+                     "flops_per_launch": flops / n_launch, "algorithmic_bytes_per_launch": alg_bytes / n_launch,
                      "kernel_operand_bytes_per_launch": (2.0 * (hi - lo) * DIM + 2.0 * Q * DIM + 8.0 * Q * launch["db_splits"] * 16) if wide else alg_bytes,
                      "hbm_GBps_algorithmic": round(alg_bytes / (knn_avg * 1e-3) / 1e9, 1),
                      "queries_rejected_by_certificate_last_step": rechecked,
@@ -481,6 +497,12 @@ def main():
         "kernels": {"k_logmel_h": kroof(lm_avg, lm_flops, lm_bytes), "k_proj_pool": kroof(pp_avg, pp_flops, pp_bytes)},
         "kernels_ms": {"k_logmel": round(lm_avg, 4), "k_proj_pool": round(pp_avg, 4), "scan": round(knn_avg, 4)},
     }
+    if shard_ms:     # this rank's share of a step outside the scan: collectives (query all-gather, bound all-reduce, list exchange) and
+        # the re-rank half of the search (float64 re-rank + exact kernel)
+        cm, rm = float(np.mean([a for a, _ in shard_ms])), float(np.mean([b for _, b in shard_ms]))
+        out["sharded"] = {"collective_ms": round(max_over_ranks(cm), 4), "rerank_ms": round(max_over_ranks(rm), 4),
+                          "rank0_collective_ms": round(cm, 4), "rank0_rerank_ms": round(rm, 4), "bound_exchange": bool(bounded),
+                          "candidates_rescored_per_query_rank0": round(launch["certificate"]["candidates_rescored"] / max(1, Q), 1)}
     if scan_unstructured:
         out["scan_unstructured_ms"] = {k_: v_["scan_ms"] for k_, v_ in scan_unstructured.items()}
         out["scan_unstructured"] = scan_unstructured

@@ -1803,6 +1803,8 @@ struct SearchCtx {
     int64_t nq = 0;
     int k = 0, l2 = 0, cslot = 0, n_parts = 0, plen = 0, cap = 0, xgroup = 1;
     bool cert = false, emit = false, use_floor = false;
+    bool canonical = false;            // the scan's scores estimate q.y / -|q - y|^2 themselves (comparable across shards); the fp32
+                                       // kernels' L2 score 2 q.y - |y|^2 lacks the -|q|^2: a cross-shard bound does not apply to it
     const float* q_use = nullptr;       // fp32 queries as the re-rank reads them (caller's buffer, or the workspace's normalised copy)
     size_t o_eps = 0, o_thr = 0, o_cnt = 0, o_fcount = 0, o_fsel = 0, o_ps = 0, o_pi = 0, o_xk = 0, o_xi = 0;
 };
@@ -2598,6 +2600,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     ctx->valid = true;
     ctx->nq = nq; ctx->k = k; ctx->l2 = l2; ctx->cslot = cslot; ctx->n_parts = n_parts; ctx->plen = plen; ctx->cap = cap; ctx->xgroup = xgroup;
     ctx->cert = cert; ctx->emit = use_hi; ctx->use_floor = use_hi; ctx->q_use = q_use;
+    ctx->canonical = use_hi || smallq_hi || !l2;
     ctx->o_eps = o_eps; ctx->o_thr = o_thr; ctx->o_cnt = o_cnt; ctx->o_fcount = o_fcount; ctx->o_fsel = o_fsel; ctx->o_ps = o_ps; ctx->o_pi = o_pi;
     ctx->o_xk = o_xk; ctx->o_xi = o_xi;
     return RADAD_OK;
@@ -2615,7 +2618,7 @@ static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* glo
     m.score = (const float*)(ws + c.o_ps); m.idx = (const int*)(ws + c.o_pi); m.n_parts = c.n_parts; m.k = k; m.dim = h->dim; m.l2 = c.l2; m.nq = nq;
     m.part_len = c.plen; m.cap = c.cap;
     m.eps = c.cert ? (const float*)(ws + c.o_eps) : nullptr; m.thr_init = c.use_floor ? (const float*)(ws + c.o_thr) : nullptr; m.qflag = nullptr;
-    m.part_cnt = c.emit ? (const int*)(ws + c.o_cnt) : nullptr; m.global_lb = c.cert ? global_lb : nullptr;
+    m.part_cnt = c.emit ? (const int*)(ws + c.o_cnt) : nullptr; m.global_lb = (c.cert && c.canonical) ? global_lb : nullptr;
     m.flag_count = flag_count; m.flag_sel = flag_sel;
     m.db = h->rows; m.db_f16 = h->f16; m.q = c.q_use; m.id_map = nullptr; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
     m.out_key = out_key_dev;

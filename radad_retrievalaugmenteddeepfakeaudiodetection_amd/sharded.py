@@ -8,6 +8,13 @@ contiguous row range [base_r, base_r + n_r) and reports GLOBAL ids (id_base = ba
   3. all_gather the per-shard (dist, id) lists       2 x [Q, k] per rank          (12*Q*k bytes per rank: latency bound)
   4. merge the G sorted lists per query by (distance, id)                          (radad_topk_merge)
 Both collectives are tiny, so on a fully connected xGMI node they are one-hop all-gathers.
+
+With `bounded=(begin, finish)` (HipFlatIndex.search_begin / search_finish) step 2 is split around one more tiny collective:
+  2a. scan the shard; per query a lower bound of the exact k-th best score of THIS shard     (radad_knn_search_begin)
+  2b. all_reduce(max) of the bounds                  [Q] float32 (4*Q bytes)
+  2c. float64 re-rank of only those candidates that can still be among the GLOBAL k best      (radad_knn_search_finish)
+Without it every shard certifies ITS OWN top k: on G shards the node re-ranks G times what one GPU would (rehearsed at G = 8:
+143 candidates per query and shard against 151 per query on one GPU), and the re-rank does not scale.
 """
 import ctypes as C
 from typing import Callable, Optional, Tuple
@@ -61,7 +68,7 @@ class ShardedSearch:
     """
 
     def __init__(self, local_search: Callable, metric: int, group=None, merge: Optional[Callable] = None,
-                 uneven: bool = False, exchange: str = "all_to_all"):
+                 uneven: bool = False, exchange: str = "all_to_all", bounded=None, timing: bool = False):
         import torch.distributed as dist
         if exchange not in ("all_to_all", "all_gather"):
             raise ValueError("exchange must be 'all_to_all' or 'all_gather'")
@@ -71,6 +78,11 @@ class ShardedSearch:
         self.merge = merge or hip_merge
         self.uneven = bool(uneven)
         self.exchange = exchange
+        # bounded = (begin, finish): begin(q [Q,D], k) -> float32 [Q] lower bounds of this shard's exact k-th best scores;
+        # finish(global_lb [Q]) -> (dist [Q,k] (float64 keys), gid [Q,k]), rows short of k are -1 filled.  Same on every rank.
+        self.bounded = bounded
+        self.timing = bool(timing)       # record (collective_ms, rerank_ms) of every search (CUDA events; read with timings())
+        self._events = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         # gloo moves host memory: device tensors are staged through the host (CPU tests; rehearsing ranks on one GPU)
@@ -108,6 +120,26 @@ class ShardedSearch:
         dist.all_to_all_single(out, t, group=self.group)
         return out.view(self.world, qr, k)
 
+    def _all_reduce_max(self, t):
+        import torch.distributed as dist
+        if t.is_cuda and self.staged:
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def timings(self):
+        """[(collective_ms, rerank_ms)] of the searches since the last call (synchronises); needs timing=True and CUDA tensors"""
+        out = []
+        for ev in self._events:
+            ev[-1].synchronize()
+            coll = sum(a.elapsed_time(b) for a, b in ev[0])
+            out.append((coll, ev[1][0].elapsed_time(ev[1][1]) if ev[1] else 0.0))
+        self._events = []
+        return out
+
     def gather_queries(self, q_local):
         return q_local if self.world == 1 else self._all_gather(q_local)
 
@@ -130,8 +162,36 @@ class ShardedSearch:
             qr_pad = qmax
         else:
             qr_pad = qr
-        q_all = self._all_gather(q_local)
-        d_loc, i_loc = self.local_search(q_all, k)
+        import contextlib
+        rec = self.timing and q_local.is_cuda
+        coll_ev, rr_ev = [], None
+
+        @contextlib.contextmanager
+        def timed(kind):
+            if not rec:
+                yield
+                return
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            yield
+            b.record()
+            if kind == "c":
+                coll_ev.append((a, b))
+            else:
+                nonlocal rr_ev
+                rr_ev = (a, b)
+
+        with timed("c"):
+            q_all = self._all_gather(q_local)
+        if self.bounded is not None:
+            begin, finish = self.bounded
+            lb = begin(q_all, k)
+            with timed("c"):
+                lb = self._all_reduce_max(lb)
+            with timed("r"):
+                d_loc, i_loc = finish(lb)
+        else:
+            d_loc, i_loc = self.local_search(q_all, k)
         Q = q_all.shape[0]
         if return_all:
             d_all = self._all_gather(d_loc).view(self.world, Q, k)
@@ -141,5 +201,9 @@ class ShardedSearch:
                 keep = torch.cat([torch.arange(r * qr_pad, r * qr_pad + c) for r, c in enumerate(counts)]).to(md.device)
                 md, mi = md[keep], mi[keep]
             return md, mi
-        md, mi = self.merge(self.metric, self._exchange(d_loc, qr_pad), self._exchange(i_loc, qr_pad), k)
+        with timed("c"):
+            xd, xi = self._exchange(d_loc, qr_pad), self._exchange(i_loc, qr_pad)
+        md, mi = self.merge(self.metric, xd, xi, k)
+        if rec:
+            self._events.append((coll_ev, rr_ev, coll_ev[-1][1]))
         return md[:qr], mi[:qr]

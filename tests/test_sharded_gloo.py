@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, metric, n, nq_locals, dim, k, exchange, out):
+def _worker(rank, world, port, metric, n, nq_locals, dim, k, exchange, out, bounded=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
@@ -48,8 +48,28 @@ def _worker(rank, world, port, metric, n, nq_locals, dim, k, exchange, out):
         md, mi = O.merge_topk(list(d.numpy()), list(i.numpy()), kk, metric)
         return torch.from_numpy(md), torch.from_numpy(mi)
 
+    # oracle stand-ins for HipFlatIndex.search_begin / search_finish: a lower bound of the shard's exact k-th best SCORE (larger is
+    # better: inner product, or minus the squared distance), then only the rows that reach the best bound any shard has
+    state = {}
+
+    def begin(q, kk):
+        d, i = local_search(q, kk)
+        sc = -d if metric == "L2" else d
+        state["res"] = (d, i, sc)
+        return sc[:, kk - 1].float().clone() if kk <= len(shard) else torch.full((len(q),), -float("inf"))
+
+    def finish(glb):
+        d, i, sc = state.pop("res")
+        # (the bound travels as float32: compare against it rounded DOWN to stay a lower bound)
+        g = torch.nextafter(glb.double().float(), torch.tensor(-float("inf"))).double()[:, None]
+        drop = sc < g
+        d = torch.where(drop, torch.full_like(d, float("inf") if metric == "L2" else -float("inf")), d)
+        i = torch.where(drop, torch.full_like(i, -1), i)
+        return d, i
+
     uneven = len(set(nq_locals)) > 1
-    s = ShardedSearch(local_search, 0 if metric == "L2" else 1, merge=merge, uneven=uneven, exchange=exchange)
+    s = ShardedSearch(local_search, 0 if metric == "L2" else 1, merge=merge, uneven=uneven, exchange=exchange,
+                      bounded=(begin, finish) if bounded else None)
     assert (s.world, s.rank) == (world, rank)
     starts = np.concatenate([[0], np.cumsum(nq_locals)])
     q_all = synth.rows(0, int(starts[-1]), dim, 977)
@@ -84,4 +104,18 @@ def test_sharded_search(world, metric, n, nq_locals, k, exchange):
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), metric, n, nq_locals, 16, k, exchange, out), nprocs=world, join=True)
+    assert dict(out) == {r: True for r in range(world)}
+
+
+@pytest.mark.parametrize("world,metric,n,nq_locals,k,exchange", [
+    (2, "L2", 1001, [5, 5], 7, "all_to_all"),
+    (4, "IP", 45, [3, 0, 5, 1], 15, "all_to_all"),      # k > shard rows: those shards offer no bound (-inf) and return all they have
+    (8, "L2", 2005, [2, 3, 1, 2, 2, 4, 2, 2], 5, "all_gather"),
+])
+def test_sharded_search_with_a_global_bound(world, metric, n, nq_locals, k, exchange):
+    """the two-phase form (search_begin -> all-reduce(max) of the k-th-best bounds -> search_finish): shards return only rows that
+    can be among the global k best (-1 filled otherwise); the merged result must still be the unsharded one"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), metric, n, nq_locals, 16, k, exchange, out, True), nprocs=world, join=True)
     assert dict(out) == {r: True for r in range(world)}

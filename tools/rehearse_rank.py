@@ -43,15 +43,51 @@ for c, eps in ((0, 0.05), (1, 0.10)):
     rows[g[mine] - lo] = all_emb[mine] + eps * scale[mine] * noise[c * Q:(c + 1) * Q][mine]
 idx = R.HipFlatIndex(D, _lib.METRIC_COSINE, 0, id_base=lo)
 idx.add_device(rows)
+# the bound the OTHER shards would contribute to the all-reduce: their search_begin over their rows (built one after the other here)
+ap_bound = a.world > 1
+glb = None
+if ap_bound:
+    for r in range(a.world):
+        if r == a.rank:
+            continue
+        l2_, h2_ = shard_bounds(N, a.world, r)
+        orow = torch.empty((h2_ - l2_, D), device=dev)
+        _lib.check(lib.radad_synth_rows(orow.data_ptr(), l2_, h2_ - l2_, D, 4321, 0, _lib.stream_ptr(dev)))
+        for c, eps in ((0, 0.05), (1, 0.10)):
+            g = (jj * 977 + c * 350003 + 17) % N
+            mine = (g >= l2_) & (g < h2_)
+            orow[g[mine] - l2_] = all_emb[mine] + eps * scale[mine] * noise[c * Q:(c + 1) * Q][mine]
+        other = R.HipFlatIndex(D, _lib.METRIC_COSINE, 0, id_base=l2_)
+        other.add_device(orow)
+        lb = other.search_begin(all_emb, K)
+        other.search_finish(None)
+        glb = lb if glb is None else torch.maximum(glb, lb)
+        del other, orow
 idx.profile(True)
-for _ in range(2):
-    idx.search_device(all_emb, K, return_f64=True)
-idx.profile_read()
-t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-t0.record()
-for _ in range(a.reps):
-    idx.search_device(all_emb, K, return_f64=True)
-t1.record(); torch.cuda.synchronize()
-ms = idx.profile_read()
-print(json.dumps({"world": a.world, "rank": a.rank, "rows": hi - lo, "queries": Q, "scan_ms": round(float(np.mean(ms)), 4),
-                  "search_ms": round(t0.elapsed_time(t1) / a.reps, 4), "launch": idx.last_launch()}))
+
+
+def one(bound):
+    lb = idx.search_begin(all_emb, K)
+    t_a = torch.cuda.Event(enable_timing=True); t_b = torch.cuda.Event(enable_timing=True)
+    t_a.record()
+    idx.search_finish(torch.maximum(lb, glb) if (bound and glb is not None) else None, return_f64=True)
+    t_b.record()
+    return t_a, t_b
+
+
+for bound in ((False, True) if ap_bound else (False,)):
+    for _ in range(2):
+        one(bound)
+    idx.profile_read()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    evs = []
+    t0.record()
+    for _ in range(a.reps):
+        evs.append(one(bound))
+    t1.record(); torch.cuda.synchronize()
+    ms = idx.profile_read()
+    la = idx.last_launch()
+    print(json.dumps({"world": a.world, "rank": a.rank, "rows": hi - lo, "queries": Q, "global_bound": bound,
+                      "scan_ms": round(float(np.mean(ms)) * la["scan_launches"], 4), "rerank_ms": round(float(np.mean([x.elapsed_time(y) for x, y in evs])), 4),
+                      "search_ms": round(t0.elapsed_time(t1) / a.reps, 4),
+                      "candidates_per_query": round(la["certificate"]["candidates_rescored"] / Q, 1), "launch": la}))
