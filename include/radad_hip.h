@@ -113,15 +113,16 @@ int radad_knn_search_ex(radad_knn_t h, const void* q_dev, int q_dtype, int64_t n
                         int64_t* out_idx_dev, double* out_key_dev, void* stream);
 /* The same search in two halves, for a store that is ROW-SHARDED over several GPUs (the reference is single-GPU,
  * vector_database.py:23; sharding is this build's, north_star).  _begin prepares the queries and scans this shard; it writes to
- * kth_lower_bound_dev [nq] a lower bound of the exact k-th best score of THIS shard per query (scores: q.y for inner product /
- * cosine, -|q - y|^2 for L2; -inf when the scan that ran offers none).  The caller takes the element-wise MAXIMUM over all shards
- * (one all-reduce of 4 nq bytes) and hands it to _finish, which then re-ranks in float64 only the candidates that can still be among
- * the GLOBAL k best -- instead of every shard certifying its own top k, 8 x the work of one GPU on 8 shards.  With a bound the rows
- * a shard returns are those of its rows that can be in the global top k (fewer than k is normal; the rest is -1 filled); merged over
- * the shards (radad_topk_merge_f64) the result is exactly the unsharded search's.  global_lower_bound_dev == NULL: _finish
- * returns this shard's own top k, i.e. _begin + _finish == radad_knn_search_ex.  One begun search per handle at a time; other
- * searches on the handle fail until it is finished. */
-int radad_knn_search_begin(radad_knn_t h, const void* q_dev, int q_dtype, int64_t nq, int k, float* kth_lower_bound_dev, void* stream);
+ * topk_lower_bounds_dev [nq, k] lower bounds of the exact scores of this shard's k best rows per query, unordered (scores: q.y
+ * for inner product / cosine, -|q - y|^2 for L2; -inf where the shard has fewer rows or the scan that ran offers none).  The
+ * caller gathers them from all shards (one all-gather of 4 nq k bytes per shard) and takes, per query, the k-th LARGEST of the
+ * G k values: a lower bound of the exact k-th best score of the whole store.  _finish, given that [nq] vector, re-ranks in
+ * float64 only the candidates that can still be among the GLOBAL k best -- instead of every shard certifying its own top k,
+ * G x the work of one GPU on G shards.  With a bound the rows a shard returns are those of its rows that can be in the global
+ * top k (fewer than k is normal; the rest is -1 filled); merged over the shards (radad_topk_merge_f64) the result is exactly the
+ * unsharded search's.  global_lower_bound_dev == NULL: _finish returns this shard's own top k, i.e. _begin + _finish ==
+ * radad_knn_search_ex.  One begun search per handle at a time; other searches on the handle fail until it is finished. */
+int radad_knn_search_begin(radad_knn_t h, const void* q_dev, int q_dtype, int64_t nq, int k, float* topk_lower_bounds_dev, void* stream);
 int radad_knn_search_finish(radad_knn_t h, const float* global_lower_bound_dev, float* out_dist_dev, int64_t* out_idx_dev,
                             double* out_key_dev, void* stream);
 /* host-buffer variant (what index.search(np.ndarray, k) does); synchronous */

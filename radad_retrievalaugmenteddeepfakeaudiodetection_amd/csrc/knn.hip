@@ -1027,7 +1027,9 @@ __device__ __forceinline__ float radix_select_kth(const float* e_sc, int NE, int
 // a_k = the k-th best score among the candidates emitted so far (-inf when there are fewer than k, or the buffer overflowed).
 //   floor_io  (optional) [nq]: raised to a_k - 2 eps -- a score k rows are KNOWN to reach, lowered by the scan's error on both
 //             sides: every row of the exact top-k scores at least that, so the rest of the store is scanned with it;
-//   lb_out    (optional) [nq]: a_k - eps, a lower bound of the EXACT k-th best score of this store (shards exchange its maximum).
+//   lb_out    (optional) [nq][k]: the k best scan scores, each lowered by eps -- lower bounds of the exact scores of k DIFFERENT rows
+//             of this store (unordered; -inf where there are fewer).  Shards exchange them: the k-th largest of all shards' values
+//             is a lower bound of the exact k-th best score of the whole store.
 struct KthParams {
     const float* score;        // [nq][cap]
     const int* cnt;            // [nq]
@@ -1046,10 +1048,20 @@ __global__ __launch_bounds__(RF_THREADS) void k_kth_floor(KthParams p) {
     const int NE = c <= p.cap ? c : 0;                                   // an overflowed buffer proves nothing (its query is rejected)
     for (int i = threadIdx.x; i < NE; i += RF_THREADS) e_sc[i] = p.score[q * p.cap + i];
     const float a_k = radix_select_kth(e_sc, NE, p.k, hist, xchg);
-    if (threadIdx.x == 0) {
-        const float e = p.eps[q];
-        if (p.floor_io && a_k > -INFINITY) p.floor_io[q] = fmaxf(p.floor_io[q], a_k - 2.f * e);
-        if (p.lb_out) p.lb_out[q] = a_k > -INFINITY ? a_k - e : -INFINITY;
+    const float e = p.eps[q];
+    if (threadIdx.x == 0 && p.floor_io && a_k > -INFINITY) p.floor_io[q] = fmaxf(p.floor_io[q], a_k - 2.f * e);
+    if (p.lb_out) {
+        float* out = p.lb_out + q * p.k;
+        if (!(a_k > -INFINITY)) {
+            for (int j = threadIdx.x; j < p.k; j += RF_THREADS) out[j] = -INFINITY;
+            return;                                                          // (block-uniform)
+        }
+        if (threadIdx.x == 0) xchg[0] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < NE; i += RF_THREADS)                   // fewer than k entries are above the k-th best
+            if (e_sc[i] > a_k) { const int pos = atomicAdd(&xchg[0], 1); if (pos < p.k) out[pos] = e_sc[i] - e; }
+        __syncthreads();
+        for (int j = min(xchg[0], p.k) + threadIdx.x; j < p.k; j += RF_THREADS) out[j] = a_k - e;
     }
 }
 
@@ -2582,17 +2594,17 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     if (!use_hi) { h->last_splits = n_splits; h->last_scan_launches = 1; }
     RADAD_HIP_CHECK(hipGetLastError());
 
-    // ---- sharded search: a lower bound of the exact k-th best score of this store, per query ------------------------------
-    // a_k - eps with a_k the k-th best scan score (the k rows with the best scan scores have exact scores >= that).  The scan
-    // score of the tile / streaming f16 kernels estimates q.y (inner product, cosine) or -|q - y|^2 (L2) whatever the plane's
-    // centring, so the bounds of different shards compare; the other kernels report no bound (-inf).
+    // ---- sharded search: lower bounds of the exact scores of this store's k best rows, per query -------------------------------
+    // (scan score - eps of the k rows with the best scan scores).  The scan score of the f16 tile kernel estimates q.y (inner
+    // product, cosine) or -|q - y|^2 (L2) whatever the plane's centring, so the bounds of different shards compare; the other
+    // kernels report none (-inf).
     if (lb_out) {
         if (use_hi && cert) {
             KthParams kp;
             kp.score = ps; kp.cnt = cand_cnt; kp.cap = emit_cap; kp.k = k; kp.eps = eps; kp.floor_io = nullptr; kp.lb_out = lb_out;
             hipLaunchKernelGGL(k_kth_floor, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)emit_cap * 4 + 1040, st, kp);
         } else {
-            hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, st, lb_out, nq, -INFINITY);
+            hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)ceil_div64(nq * k, 256)), dim3(256), 0, st, lb_out, nq * k, -INFINITY);
         }
         RADAD_HIP_CHECK(hipGetLastError());
     }

@@ -10,8 +10,9 @@ contiguous row range [base_r, base_r + n_r) and reports GLOBAL ids (id_base = ba
 Both collectives are tiny, so on a fully connected xGMI node they are one-hop all-gathers.
 
 With `bounded=(begin, finish)` (HipFlatIndex.search_begin / search_finish) step 2 is split around one more tiny collective:
-  2a. scan the shard; per query a lower bound of the exact k-th best score of THIS shard     (radad_knn_search_begin)
-  2b. all_reduce(max) of the bounds                  [Q] float32 (4*Q bytes)
+  2a. scan the shard; per query lower bounds of the exact scores of its k best rows          (radad_knn_search_begin)
+  2b. all_gather of the bounds                       [Q, k] float32 per rank (4*Q*k bytes); the k-th largest of a query's G*k
+      values is a lower bound of the exact k-th best score of the WHOLE store
   2c. float64 re-rank of only those candidates that can still be among the GLOBAL k best      (radad_knn_search_finish)
 Without it every shard certifies ITS OWN top k: on G shards the node re-ranks G times what one GPU would (rehearsed at G = 8:
 143 candidates per query and shard against 151 per query on one GPU), and the re-rank does not scale.
@@ -78,8 +79,9 @@ class ShardedSearch:
         self.merge = merge or hip_merge
         self.uneven = bool(uneven)
         self.exchange = exchange
-        # bounded = (begin, finish): begin(q [Q,D], k) -> float32 [Q] lower bounds of this shard's exact k-th best scores;
-        # finish(global_lb [Q]) -> (dist [Q,k] (float64 keys), gid [Q,k]), rows short of k are -1 filled.  Same on every rank.
+        # bounded = (begin, finish): begin(q [Q,D], k) -> float32 [Q, k] lower bounds of the exact scores of this shard's k best rows
+        # (or [Q]: of its k-th best alone); finish(global_lb [Q]) -> (dist [Q,k] (float64 keys), gid [Q,k]), rows short of k are
+        # -1 filled.  Same on every rank.
         self.bounded = bounded
         self.timing = bool(timing)       # record (collective_ms, rerank_ms) of every search (CUDA events; read with timings())
         self._events = []
@@ -187,7 +189,11 @@ class ShardedSearch:
             begin, finish = self.bounded
             lb = begin(q_all, k)
             with timed("c"):
-                lb = self._all_reduce_max(lb)
+                if lb.dim() == 2:      # the k best of every shard: the k-th largest of the union bounds the global k-th best
+                    allb = self._all_gather(lb).view(self.world, lb.shape[0], lb.shape[1])
+                    lb = torch.topk(allb.permute(1, 0, 2).reshape(lb.shape[0], -1), k, dim=1).values[:, k - 1].contiguous()
+                else:
+                    lb = self._all_reduce_max(lb)
             with timed("r"):
                 d_loc, i_loc = finish(lb)
         else:

@@ -159,20 +159,29 @@ class HipFlatIndex:
 
     def search_begin(self, q, k: int):
         """first half of a search over a row shard (sharded.py): prepares the queries and scans this shard; returns a float32 CUDA
-        tensor [nq] -- per query a lower bound of the exact k-th best score of THIS shard (q.y / -|q - y|^2; -inf when none).
-        The caller all-reduces (max) it over the shards and passes the result to search_finish."""
+        tensor [nq, k] -- per query lower bounds of the exact scores of this shard's k best rows (q.y / -|q - y|^2; -inf where
+        there is none).  The caller gathers them from all shards; the k-th largest of a query's G k values (global_bound below) is
+        what search_finish takes."""
         import torch
         _lib.require_cuda(q, "q")
         bf16 = q.dtype == torch.bfloat16
         q = q.contiguous() if bf16 else q.contiguous().float()
         if q.dim() != 2 or q.shape[1] != self.d:
             raise ValueError(f"search expects [nq, {self.d}], got {tuple(q.shape)}")
-        lb = torch.empty((q.shape[0],), device=q.device, dtype=torch.float32)
+        lb = torch.empty((q.shape[0], int(k)), device=q.device, dtype=torch.float32)
         with torch.cuda.device(q.device):
             _lib.check(self._lib.radad_knn_search_begin(self._h, q.data_ptr(), _lib.Q_BF16 if bf16 else _lib.Q_F32, q.shape[0], int(k),
                                                         lb.data_ptr(), _lib.stream_ptr(q.device)), "radad_knn_search_begin")
         self._begun = (q, int(k))          # (keeps the queries alive until the second half has read them)
         return lb
+
+    @staticmethod
+    def global_bound(lb_all, k: int):
+        """lb_all [G, nq, k] (every shard's search_begin result) -> [nq]: the k-th largest of each query's G k lower bounds = a lower
+        bound of the exact k-th best score over all shards"""
+        import torch
+        G, nq, kk = lb_all.shape
+        return torch.topk(lb_all.permute(1, 0, 2).reshape(nq, G * kk), int(k), dim=1).values[:, int(k) - 1].contiguous()
 
     def search_finish(self, global_lb=None, return_f64: bool = False):
         """second half: float64 re-rank of what can still be among the GLOBAL k best (global_lb: the element-wise maximum of the

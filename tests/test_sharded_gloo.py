@@ -56,6 +56,8 @@ def _worker(rank, world, port, metric, n, nq_locals, dim, k, exchange, out, boun
         d, i = local_search(q, kk)
         sc = -d if metric == "L2" else d
         state["res"] = (d, i, sc)
+        if bounded == "topk":      # the library's form: bounds of the k best rows, -inf where the shard has fewer
+            return torch.nan_to_num(sc.float(), nan=-float("inf"), neginf=-float("inf")).clone()
         return sc[:, kk - 1].float().clone() if kk <= len(shard) else torch.full((len(q),), -float("inf"))
 
     def finish(glb):
@@ -107,15 +109,16 @@ def test_sharded_search(world, metric, n, nq_locals, k, exchange):
     assert dict(out) == {r: True for r in range(world)}
 
 
-@pytest.mark.parametrize("world,metric,n,nq_locals,k,exchange", [
-    (2, "L2", 1001, [5, 5], 7, "all_to_all"),
-    (4, "IP", 45, [3, 0, 5, 1], 15, "all_to_all"),      # k > shard rows: those shards offer no bound (-inf) and return all they have
-    (8, "L2", 2005, [2, 3, 1, 2, 2, 4, 2, 2], 5, "all_gather"),
+@pytest.mark.parametrize("world,metric,n,nq_locals,k,exchange,form", [
+    (2, "L2", 1001, [5, 5], 7, "all_to_all", "topk"),
+    (4, "IP", 45, [3, 0, 5, 1], 15, "all_to_all", "topk"),     # k > shard rows: a shard's missing bounds are -inf, the union still has k
+    (4, "IP", 45, [3, 0, 5, 1], 15, "all_to_all", "kth"),      # the weaker one-value form (all-reduce max): such shards offer nothing
+    (8, "L2", 2005, [2, 3, 1, 2, 2, 4, 2, 2], 5, "all_gather", "topk"),
 ])
-def test_sharded_search_with_a_global_bound(world, metric, n, nq_locals, k, exchange):
+def test_sharded_search_with_a_global_bound(world, metric, n, nq_locals, k, exchange, form):
     """the two-phase form (search_begin -> all-reduce(max) of the k-th-best bounds -> search_finish): shards return only rows that
     can be among the global k best (-1 filled otherwise); the merged result must still be the unsharded one"""
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), metric, n, nq_locals, 16, k, exchange, out, True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), metric, n, nq_locals, 16, k, exchange, out, form), nprocs=world, join=True)
     assert dict(out) == {r: True for r in range(world)}

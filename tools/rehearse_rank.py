@@ -61,7 +61,7 @@ if ap_bound:
         other.add_device(orow)
         lb = other.search_begin(all_emb, K)
         other.search_finish(None)
-        glb = lb if glb is None else torch.maximum(glb, lb)
+        glb = lb if glb is None else torch.cat([glb, lb], 1)      # [Q, (G - 1) k] lower bounds from the other shards
         del other, orow
 idx.profile(True)
 
@@ -70,7 +70,10 @@ def one(bound):
     lb = idx.search_begin(all_emb, K)
     t_a = torch.cuda.Event(enable_timing=True); t_b = torch.cuda.Event(enable_timing=True)
     t_a.record()
-    idx.search_finish(torch.maximum(lb, glb) if (bound and glb is not None) else None, return_f64=True)
+    g = None
+    if bound and glb is not None:
+        g = torch.topk(torch.cat([glb, lb], 1), K, dim=1).values[:, K - 1].contiguous()
+    idx.search_finish(g, return_f64=True)
     t_b.record()
     return t_a, t_b
 
