@@ -1841,6 +1841,7 @@ struct radad_knn_s {
     float* cmu = nullptr;        // [dim] the common component, or nullptr: plane of the rows themselves
     float mu_norm = 0.f, mu_sq = 0.f;   // |mu| (rounded up: it enters error bounds) and |mu|^2 as summed on the device
     float* rbias = nullptr;      // [hi_cap] per-row bias of a centred plane: |y - mu|^2 (L2) or mu.y (IP / cosine)
+    int uniform_e = HI_E_PER_ROW; // one power-of-two scale 2^e for every row of the plane (rows of one magnitude), or HI_E_PER_ROW
     // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
     // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
     // The counters of search i land in slot i % 2 and are CONSUMED by search i + 2 behind a wait on that slot's event (long due by
@@ -1957,13 +1958,25 @@ __global__ __launch_bounds__(256) void k_col_final(const float* __restrict__ par
     if (threadIdx.x == 0) { out2[0] = mu2; out2[1] = red[0] / (float)m; }
 }
 
+// max |x - mu| over the elements of the first m rows (non-negative floats order like their bit patterns)
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ rows, const float* __restrict__ mu, int64_t m, int dim,
+                                                unsigned* __restrict__ out /*[2]: max, and min over rows of the row maximum*/) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    float mx = 0.f;
+    for (int i = lane; i < dim; i += 64) mx = fmaxf(mx, fabsf(rows[row * dim + i] - (mu ? mu[i] : 0.f)));
+    mx = wave_max(mx);
+    if (lane == 0) { atomicMax(&out[0], __float_as_uint(mx)); atomicMin(&out[1], __float_as_uint(mx)); }
+}
+
 static void knn_drop_plane(radad_knn_t h) {
     if (h->hi) (void)hipFree(h->hi);
     if (h->rscale) (void)hipFree(h->rscale);
     if (h->cmu) (void)hipFree(h->cmu);
     if (h->rbias) (void)hipFree(h->rbias);
     h->hi = nullptr; h->rscale = nullptr; h->cmu = nullptr; h->rbias = nullptr; h->mu_norm = 0.f; h->mu_sq = 0.f;
-    h->hi_rows = 0; h->hi_cap = 0;
+    h->hi_rows = 0; h->hi_cap = 0; h->uniform_e = HI_E_PER_ROW;
 }
 
 // Decide whether the plane is CENTRED and compute mu (one-off, when the plane is built; synchronises).  Centred when the common
@@ -2012,7 +2025,31 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
         (void)hipDeviceSynchronize();
         knn_drop_plane(h);
         const bool centred = knn_choose_centre(h, st);
-        const bool per_row = h->metric != RADAD_METRIC_COSINE || centred;
+        // One scale for the whole plane when the rows are of one magnitude (the largest row maximum within 2^6 of the smallest over
+        // the rows the store holds now: clip embeddings are; rows scaled over 2^22, as a test does, are not): the scan then needs
+        // no per-score arithmetic.  2^e puts the largest element in [2^12, 2^13): a later row up to 8x larger still fits f16, beyond
+        // that it saturates and its (measured) residual rejects queries.  Un-centred cosine rows have |x| <= 1: e = 14 as before.
+        if (h->metric != RADAD_METRIC_COSINE || centred) {
+            unsigned* mm = nullptr;
+            unsigned host[2] = {0u, 0x7f800000u};
+            const int64_t m = std::min<int64_t>(h->ntotal, KM_MAX_ROWS);
+            if (m > 0 && hipMalloc(&mm, 2 * sizeof(unsigned)) == hipSuccess) {
+                (void)hipMemcpyAsync(mm, host, sizeof(host), hipMemcpyHostToDevice, st);
+                hipLaunchKernelGGL(k_absmax, dim3((unsigned)ceil_div64(m, 4)), dim3(256), 0, st, (const float*)h->rows, (const float*)h->cmu, m, h->dim, mm);
+                if (hipMemcpyAsync(host, mm, sizeof(host), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+                    float mx, mn;
+                    memcpy(&mx, &host[0], 4); memcpy(&mn, &host[1], 4);
+                    if (mx > 0.f && mx < INFINITY && mn > 0.f && mx <= mn * 64.f) {
+                        int fe;
+                        (void)frexpf(mx, &fe);
+                        h->uniform_e = std::max(-100, std::min(100, 13 - fe));
+                    }
+                }
+                (void)hipFree(mm);
+            }
+            (void)hipGetLastError();
+        }
+        const bool per_row = (h->metric != RADAD_METRIC_COSINE || centred) && h->uniform_e == HI_E_PER_ROW;
         if (hipMalloc(&h->hi, (size_t)h->capacity * h->dim * 2) != hipSuccess ||
             (per_row && hipMalloc(&h->rscale, (size_t)h->capacity * sizeof(float)) != hipSuccess) ||
             (centred && hipMalloc(&h->rbias, (size_t)h->capacity * sizeof(float)) != hipSuccess)) {
@@ -2038,7 +2075,7 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
         hp.n = h->ntotal - from; hp.dim = h->dim;
         // un-centred cosine rows have |x| <= 1: one scale for the whole store (no per-score arithmetic in the scan);
         // an fp16 store is its own plane: statistics only, un-scaled
-        hp.fixed_e = h->f16 ? 0 : ((h->metric == RADAD_METRIC_COSINE && !h->cmu) ? 14 : HI_E_PER_ROW);
+        hp.fixed_e = h->f16 ? 0 : ((h->metric == RADAD_METRIC_COSINE && !h->cmu) ? 14 : h->uniform_e);
         hp.l2 = h->metric == RADAD_METRIC_L2 ? 1 : 0; hp.exact_ops = h->f16 ? 1 : 0;
         // (a plane that exists keeps its centring for the statistics-only calls too: the statistics are those of ITS operands)
         hp.mu = h->cmu; hp.mu_norm = h->mu_norm; hp.mu_sq = h->mu_sq; hp.biased = 0;
@@ -2439,7 +2476,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         KnnHiParams wp;
         wp.db = h->f16 ? (const void*)h->rows : (const void*)h->hi;
         wp.rscale = h->f16 ? nullptr : h->rscale;
-        wp.uscale = (!h->f16 && h->metric == RADAD_METRIC_COSINE) ? 0x1p-14f : 1.0f;
+        wp.uscale = h->f16 ? 1.0f : (h->uniform_e != HI_E_PER_ROW ? ldexpf(1.0f, -h->uniform_e) : (h->metric == RADAD_METRIC_COSINE ? 0x1p-14f : 1.0f));
         // bias of the scale + bias variant: a centred plane has its own (|y - mu|^2 or mu.y); un-centred L2 uses |y|^2 as stored
         wp.rbias = mu ? h->rbias : h->ynorm; wp.bias_sign = l2 ? -1.f : 1.f; wp.mult = l2 ? 2.f : 1.f; wp.qconst = biased ? qconst : nullptr;
         wp.q = qh; wp.qscale = qscale;
@@ -2459,12 +2496,12 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             }
         }
 #endif
-        const int rsc = biased ? 2 : (wp.rscale ? 1 : 0);
+        const int rsc = biased ? (wp.rscale ? 2 : 3) : (wp.rscale ? 1 : 0);
         const size_t lds = knn_hi_lds_bytes();
-        const void* fns[3] = {reinterpret_cast<const void*>(k_knn_hi<0>), reinterpret_cast<const void*>(k_knn_hi<1>),
-                              reinterpret_cast<const void*>(k_knn_hi<2>)};
-        const void* sfns[3] = {reinterpret_cast<const void*>(k_knn_hi_sample<0>), reinterpret_cast<const void*>(k_knn_hi_sample<1>),
-                               reinterpret_cast<const void*>(k_knn_hi_sample<2>)};
+        const void* fns[4] = {reinterpret_cast<const void*>(k_knn_hi<0>), reinterpret_cast<const void*>(k_knn_hi<1>),
+                              reinterpret_cast<const void*>(k_knn_hi<2>), reinterpret_cast<const void*>(k_knn_hi<3>)};
+        const void* sfns[4] = {reinterpret_cast<const void*>(k_knn_hi_sample<0>), reinterpret_cast<const void*>(k_knn_hi_sample<1>),
+                               reinterpret_cast<const void*>(k_knn_hi_sample<2>), reinterpret_cast<const void*>(k_knn_hi_sample<3>)};
         RADAD_HIP_CHECK(hipFuncSetAttribute(fns[rsc], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RADAD_HIP_CHECK(hipFuncSetAttribute(sfns[rsc], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         // sample pre-pass: the (k + margin)-th best score over the first rows of the store is a score at least k rows reach, so the
@@ -2473,10 +2510,11 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         {
             KnnHiParams sp = wp;
             sp.n = (int64_t)s_splits * KW_M; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
-            const dim3 sg((unsigned)(sp.n_qtiles * sp.n_splits)), sb(KW_THREADS);
+            const dim3 sg((unsigned)((sp.n_qtiles <= 8 ? sp.n_qtiles : (sp.n_qtiles + 7) / 8 * 8) * sp.n_splits)), sb(KW_THREADS);
             if (rsc == 0) hipLaunchKernelGGL(k_knn_hi_sample<0>, sg, sb, lds, st, sp);
             else if (rsc == 1) hipLaunchKernelGGL(k_knn_hi_sample<1>, sg, sb, lds, st, sp);
-            else hipLaunchKernelGGL(k_knn_hi_sample<2>, sg, sb, lds, st, sp);
+            else if (rsc == 2) hipLaunchKernelGGL(k_knn_hi_sample<2>, sg, sb, lds, st, sp);
+            else hipLaunchKernelGGL(k_knn_hi_sample<3>, sg, sb, lds, st, sp);
             hipLaunchKernelGGL(k_thr_from_parts, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, ps, pi, sp.n_splits * 8, 2,
                                k + margin, nq, thr_init, (const float*)eps);
             wp.thr_init = thr_init;
@@ -2493,12 +2531,13 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             knn_geometry_wide(rp.n, nq, &gq, &gs, &gc);
             rp.n_splits = gs; rp.chunk_rows = gc;
             h->last_splits = gs;
-            const dim3 g2((unsigned)(gq * gs));
+            const dim3 g2((unsigned)((gq <= 8 ? gq : (gq + 7) / 8 * 8) * gs));      // (more than 8 query tiles: whole groups of 8, see the kernel)
             h->prof.begin(st);      // the event pair brackets a scan launch only (the kernel the roofline is quoted on; the phases of one
                                     // search are two entries)
             if (rsc == 0) hipLaunchKernelGGL(k_knn_hi<0>, g2, b, lds, st, rp);
             else if (rsc == 1) hipLaunchKernelGGL(k_knn_hi<1>, g2, b, lds, st, rp);
-            else hipLaunchKernelGGL(k_knn_hi<2>, g2, b, lds, st, rp);
+            else if (rsc == 2) hipLaunchKernelGGL(k_knn_hi<2>, g2, b, lds, st, rp);
+            else hipLaunchKernelGGL(k_knn_hi<3>, g2, b, lds, st, rp);
             h->prof.end(st);
         };
         h->last_scan_launches = 0;
@@ -2529,7 +2568,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         SmallQHiParams sp;
         sp.db = h->f16 ? (const _Float16*)h->rows : h->hi;
         sp.rscale = h->f16 ? nullptr : h->rscale;
-        sp.uscale = (!h->f16 && h->metric == RADAD_METRIC_COSINE) ? 0x1p-14f : 1.0f;
+        sp.uscale = h->f16 ? 1.0f : (h->uniform_e != HI_E_PER_ROW ? ldexpf(1.0f, -h->uniform_e) : (h->metric == RADAD_METRIC_COSINE ? 0x1p-14f : 1.0f));
         sp.rbias = biased ? (mu ? h->rbias : h->ynorm) : nullptr; sp.bias_sign = l2 ? -1.f : 1.f; sp.mult = l2 ? 2.f : 1.f;
         sp.qconst = biased ? qconst : nullptr;
         sp.q = qh; sp.qscale = qscale; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel;
