@@ -155,6 +155,10 @@ int radad_knn_last_scan_kind(radad_knn_t h, int* kind);
 /* scan-kernel launches of the last search (the certified tile scan covers a large store in two: the first eighth with the
  * sample's admission floor, the rest with the floor the first eighth's candidates give); radad_knn_profile_read has one entry each */
 int radad_knn_last_scan_launches(radad_knn_t h, int* n_launches);
+/* the f16 plane the certified scans read, once a search has built it: built (0/1); centred = the common component (column mean)
+ * of the rows is subtracted before rounding (stores of embeddings that share most of their mean); one_scale = one power-of-two
+ * scale for all rows (rows of one magnitude: the scan applies no per-score arithmetic) */
+int radad_knn_plane_info(radad_knn_t h, int* built, int* centred, int* one_scale);
 /* Certificate of the most recent search (see radad_knn_search_f64): number of queries the float64 re-rank could NOT certify
  * and that were therefore searched again by the exact float64 kernel (results are exact either way).  Synchronises with
  * that search.  radad_knn_last_certificate additionally returns the batch size and stats6 = {rejected queries, sum over
@@ -215,6 +219,9 @@ int radad_ivf_search(radad_ivf_t h, const float* q_dev, int64_t nq, int k, int n
                                                                     synchronously */
 int radad_ivf_reconstruct(radad_ivf_t h, const int64_t* idx_dev, int64_t n, float* out_dev, void* stream);
 
+/* out[r] = the k-th largest of in[r][0..m) (1 <= k <= m <= 1280; NaN ranks lowest).  For the sharded search: m = G k lower bounds per
+ * query gathered from G shards' radad_knn_search_begin -> the bound radad_knn_search_finish takes. */
+int radad_kth_largest(const float* in_dev, int64_t n, int m, int k, float* out_dev, int device, void* stream);
 /* row L2 normalisation x / (|x| + 1e-12)  (vector_database.py:100-105); in-place allowed */
 int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int device, void* stream);
 

@@ -1787,6 +1787,40 @@ __global__ __launch_bounds__(256) void k_filter_topk(const float* __restrict__ i
     }
 }
 
+// out[r] = the k-th largest of in[r][0..m) (NaN ranks lowest).  One wave per row, a lane holds up to KTH_PER_LANE values; k - 1 rounds
+// of "wave-wide maximum, its first holder drops it".  The sharded search's bound: m = G k lower bounds per query.
+constexpr int KTH_PER_LANE = 20;         // m <= 1280 (8 shards x k = 128, or 40 x 32)
+__global__ __launch_bounds__(256) void k_kth_largest(const float* __restrict__ in, int64_t n, int m, int k, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float v[KTH_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < KTH_PER_LANE; ++i) {
+        const int c = lane + 64 * i;
+        const float x = c < m ? in[r * m + c] : -INFINITY;
+        v[i] = x == x ? x : -INFINITY;
+    }
+    float best = -INFINITY;
+    for (int round = 0; round < k; ++round) {
+        float mine = v[0];
+#pragma unroll
+        for (int i = 1; i < KTH_PER_LANE; ++i) mine = fmaxf(mine, v[i]);
+        best = wave_max(mine);
+        if (round + 1 == k) break;
+        // the lowest lane holding `best` drops one copy of it
+        const unsigned long long holders = __ballot(mine == best);
+        if (holders == 0ull) break;                                   // (only when everything left is -inf)
+        if (lane == __ffsll((long long)holders) - 1) {
+            bool done = false;
+#pragma unroll
+            for (int i = 0; i < KTH_PER_LANE; ++i)
+                if (!done && v[i] == best) { v[i] = -INFINITY; done = true; }
+        }
+    }
+    if (lane == 0) out[r] = best;
+}
+
 constexpr size_t knn_lds_bytes() { return sizeof(float) * (2 * KT_M * KT_LD + 2 * KT_N * KT_LD); }
 static_assert(KT_N * KS_LD <= 2 * KT_M * KT_LD + 2 * KT_N * KT_LD, "score tile must fit in the tile buffers");
 
@@ -2878,6 +2912,15 @@ int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, i
     return RADAD_OK;
 }
 
+int radad_knn_plane_info(radad_knn_t h, int* built, int* centred, int* one_scale) {
+    RADAD_REQUIRE(h, "NULL handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (built) *built = (h->hi != nullptr && h->hi_rows > 0) ? 1 : 0;
+    if (centred) *centred = h->cmu != nullptr ? 1 : 0;
+    if (one_scale) *one_scale = (h->hi != nullptr && h->rscale == nullptr) ? 1 : 0;
+    return RADAD_OK;
+}
+
 int radad_knn_last_scan_launches(radad_knn_t h, int* n_launches) {
     RADAD_REQUIRE(h && n_launches, "NULL argument");
     *n_launches = h->last_scan_launches;
@@ -3105,6 +3148,16 @@ int radad_filter_topk(const float* in_dist_dev, const int64_t* in_idx_dev, int64
     DeviceGuard g(device);
     hipLaunchKernelGGL(k_filter_topk, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, (hipStream_t)stream, in_dist_dev, in_idx_dev,
                        nq, k_in, k_keep, row_tags_dev, ntotal, id_base, excl_sorted_dev, n_excl, out_dist_dev, out_idx_dev);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
+int radad_kth_largest(const float* in_dev, int64_t n, int m, int k, float* out_dev, int device, void* stream) {
+    RADAD_REQUIRE(n >= 0 && m >= 1 && m <= 64 * KTH_PER_LANE && k >= 1 && k <= m, "radad_kth_largest: bad shape (m <= %d, 1 <= k <= m)", 64 * KTH_PER_LANE);
+    if (n == 0) return RADAD_OK;
+    RADAD_REQUIRE(in_dev && out_dev, "radad_kth_largest: NULL buffer");
+    DeviceGuard g(device);
+    hipLaunchKernelGGL(k_kth_largest, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, (hipStream_t)stream, in_dev, n, m, k, out_dev);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
 }

@@ -191,7 +191,11 @@ class ShardedSearch:
             with timed("c"):
                 if lb.dim() == 2:      # the k best of every shard: the k-th largest of the union bounds the global k-th best
                     allb = self._all_gather(lb).view(self.world, lb.shape[0], lb.shape[1])
-                    lb = torch.topk(allb.permute(1, 0, 2).reshape(lb.shape[0], -1), k, dim=1).values[:, k - 1].contiguous()
+                    if allb.is_cuda:
+                        from .vector_database import HipFlatIndex
+                        lb = HipFlatIndex.global_bound(allb, k)
+                    else:
+                        lb = torch.topk(allb.permute(1, 0, 2).reshape(lb.shape[0], -1), k, dim=1).values[:, k - 1].contiguous()
                 else:
                     lb = self._all_reduce_max(lb)
             with timed("r"):

@@ -181,7 +181,12 @@ class HipFlatIndex:
         bound of the exact k-th best score over all shards"""
         import torch
         G, nq, kk = lb_all.shape
-        return torch.topk(lb_all.permute(1, 0, 2).reshape(nq, G * kk), int(k), dim=1).values[:, int(k) - 1].contiguous()
+        flat = lb_all.permute(1, 0, 2).reshape(nq, G * kk).contiguous().float()
+        out = torch.empty((nq,), device=flat.device, dtype=torch.float32)
+        with torch.cuda.device(flat.device):
+            _lib.check(_lib.load().radad_kth_largest(flat.data_ptr(), nq, G * kk, int(k), out.data_ptr(), flat.device.index,
+                                                     _lib.stream_ptr(flat.device)), "radad_kth_largest")
+        return out
 
     def search_finish(self, global_lb=None, return_f64: bool = False):
         """second half: float64 re-rank of what can still be among the GLOBAL k best (global_lb: the element-wise maximum of the
@@ -214,6 +219,12 @@ class HipFlatIndex:
             _lib.check(self._lib.radad_knn_reconstruct(self._h, flat.data_ptr(), flat.numel(), out.data_ptr(),
                                                        _lib.stream_ptr(idx.device)), "radad_knn_reconstruct")
         return out.reshape(*idx.shape, self.d)
+
+    def plane_info(self):
+        """{"built", "centred", "one_scale"} of the f16 plane the certified scans read (radad_knn_plane_info)"""
+        b, c, o = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._lib.radad_knn_plane_info(self._h, C.byref(b), C.byref(c), C.byref(o)))
+        return {"built": bool(b.value), "centred": bool(c.value), "one_scale": bool(o.value)}
 
     def last_launch(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()

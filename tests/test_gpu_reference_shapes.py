@@ -103,6 +103,10 @@ def test_reference_store_shapes_take_the_certified_kernels(gpu, knn_oracle_lib, 
         return I
 
     I256 = check(B, "hi_tile", 64)                                    # training / evaluation batches (pipeline.py:478-480)
+    # embeddings that share most of their mean are scanned on a CENTRED plane (the error bound scales with |y - mean|, not |y|);
+    # random directions are not centred; rows of one magnitude share one scale (no per-score arithmetic in the scan)
+    plane = idx.plane_info()
+    assert plane["built"] and plane["centred"] == (data == "embedding_like") and plane["one_scale"], plane
     I1 = check(1, "hi_smallq", 1)                                     # predict(): one query streams the f16 plane (HBM-bound)
     assert torch.equal(I1[0], I256[0])
     # 16 queries of dim 5376 do not fit the streaming kernel's LDS (172 KB): they take the tile kernel; dim 3584 streams
@@ -291,3 +295,19 @@ def test_device_offsets_outside_the_wave_buffer_are_clamped_and_reported(gpu):
     out = fe.embed_clips(wave, good)
     fe.check_device_plan()
     assert torch.equal(out, ref)
+
+
+def test_kth_largest_kernel(gpu):
+    """radad_kth_largest (the sharded search's global bound: k-th largest of the G k lower bounds of a query) == torch.topk"""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for G, nq, k in ((8, 1000, 10), (2, 33, 15), (8, 50, 128), (5, 7, 1)):
+        x = torch.randn((G, nq, k), generator=g)
+        x[0, 0, :] = float("-inf")                       # a shard with nothing to offer
+        x[1, 1, 0] = float("nan")                        # ranks lowest
+        if k > 1:
+            x[:, 2, :] = 0.25                            # all equal
+        want = torch.topk(torch.nan_to_num(x, nan=float("-inf")).permute(1, 0, 2).reshape(nq, G * k), k, dim=1).values[:, k - 1]
+        got = HipFlatIndex.global_bound(x.to(gpu), k).cpu()
+        assert torch.equal(got, want), (G, nq, k)

@@ -37,8 +37,8 @@ for _ in range(a.reps):
     D, I = idx.search_device(q, a.k)
 t1.record(); torch.cuda.synchronize()
 ms = idx.profile_read()
-scan = sum(ms) / max(len(ms), 1)
+scan = sum(ms) / max(len(ms), 1) * idx.last_launch()["scan_launches"]
 flops = 2.0 * a.nq * a.rows * a.dim
 print(json.dumps({"rows": a.rows, "dim": a.dim, "nq": a.nq, "f16": a.f16, "metric": a.metric, "scan_ms": round(scan, 4),
                   "search_ms": round(t0.elapsed_time(t1) / a.reps, 4), "scan_TFLOPs": round(flops / scan / 1e9, 1),
-                  "launch": idx.last_launch()}))
+                  "plane": idx.plane_info(), "launch": idx.last_launch()}))
