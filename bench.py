@@ -354,8 +354,10 @@ def main():
         qu = torch.empty((B, DIM), device=dev, dtype=torch.float32)
         _lib.check(lib.radad_synth_rows(qu.data_ptr(), 0, B, DIM, 977, local_rank, _lib.stream_ptr(dev)))
         scan_unstructured = {}
+        # (the L2 copy holds the rows AS STORED by the cosine index -- unit norm: what an L2 index over normalised embeddings holds)
         l2_index = R.HipFlatIndex(DIM, _lib.METRIC_L2, local_rank, store_f16=f16_store)
-        l2_index.add_device(rows)
+        for r0 in range(0, hi - lo, 1 << 17):
+            l2_index.add_device(vdb.index.reconstruct_batch(torch.arange(lo + r0, min(hi, lo + r0 + (1 << 17)), device=dev)))
         for name, index in (("cosine", vdb.index), ("l2", l2_index)):
             index.profile(False)
             for _ in range(3):

@@ -2122,14 +2122,13 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
     return !want_plane || have_plane || h->f16;
 }
 
-// wide kernel: 256-query tiles, one workgroup per CU; two rounds of workgroups keep the tail short
+// wide kernel: 256-query tiles, one workgroup per CU; two rounds of workgroups keep the tail short.  (The list-based scan of
+// rounds 1-2 also needed >= 64 chunks so that no 16-entry list was used up; the emit-mode scan has no lists: a sharded batch of
+// 32 query tiles now runs 16 chunks of 31 tiles instead of 64 chunks of 8, i.e. a quarter of the per-workgroup start-up cost.)
 static void knn_geometry_wide(int64_t n, int64_t nq, int* n_qtiles, int* n_splits, int64_t* chunk_rows) {
     const int qt = (int)ceil_div64(nq, KW_N);
     const int64_t tiles = ceil_div64(n, KW_M);
-    // >= 512 workgroups, and >= 64 chunks however many query tiles there are: every (query, chunk) keeps 16 candidates, and on
-    // stores of near-duplicates (the benchmark: ~150 rows within the certificate's threshold per query) 16 chunks would see
-    // one list in thirty used up and send a third of the batch to the exact kernel (the 8-GPU per-rank shape: 32 query tiles)
-    int64_t want = std::max<int64_t>(ceil_div64(512, qt), 64);
+    int64_t want = ceil_div64(512, qt);
     want = std::min<int64_t>(want, tiles);
     want = std::max<int64_t>(8, ceil_div64(want, 8) * 8);
     want = std::min<int64_t>(want, 1024);
