@@ -908,6 +908,104 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams 
     }
 }
 
+// ---- the same streaming scan, K SPLIT over the four waves of a workgroup (small stores of wide rows) ---------------------------
+// The reference's own online search is ONE query of dim 5376 against 25 423 rows (pipeline.py:1038-1054, config.py:48-56): 1 589
+// 16-row steps in all.  With a wave per row slice that is at most 1 589 waves (6 per CU) each streaming 10.5 KB rows: too few loads
+// in flight to cover the HBM latency (measured 2.0 TB/s).  Here the four waves of a workgroup take a quarter of the row's elements
+// each for the SAME 16 rows, so every 16-row step keeps 4 waves busy (6 356 wave-steps over the store); their partial products
+// meet in LDS, are added in a fixed order (deterministic) by wave 0, which also keeps the workgroup's top-k lists.
+template <int KSEL>
+__global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq_ksplit(SmallQHiParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int qld = p.dim + 8;
+    _Float16* sQ = reinterpret_cast<_Float16*>(smem);             // [nq][dim + 8]
+    float2* sCand = reinterpret_cast<float2*>(sQ + p.nq * qld);   // [16 q][SQ_SLOTS] (wave 0's)
+    int* sCnt = reinterpret_cast<int*>(sCand + 4 * SQ_NQ * 24);   // [16]
+    f32x4* sPart = reinterpret_cast<f32x4*>(sCand + SQ_NQ * SQ_SLOTS);   // [2 parities][3 waves][64 lanes]: partial sums of waves 1-3 (inside the slot area)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    for (int i = tid; i < p.nq * (p.dim >> 3); i += SQ_THREADS) {
+        const int qq = i / (p.dim >> 3), c8 = i % (p.dim >> 3);
+        *reinterpret_cast<f16x8*>(sQ + qq * qld + c8 * 8) = *reinterpret_cast<const f16x8*>(p.q + (int64_t)qq * p.dim + c8 * 8);
+    }
+    if (tid < SQ_NQ) sCnt[tid] = 0;
+    __syncthreads();
+
+    const int64_t w_begin = (int64_t)blockIdx.x * p.rows_per_wave;      // (here: rows per WORKGROUP)
+    const int64_t w_end = min(w_begin + p.rows_per_wave, p.n);
+    const u64 SENT = pack_key(-INFINITY, IDX_SENTINEL);
+    u64 lst[KSEL];                       // wave 0, lanes 0..15 (lane = query)
+#pragma unroll
+    for (int j = 0; j < KSEL; ++j) lst[j] = SENT;
+    float thr = -INFINITY;
+    const float qs = r16 < p.nq ? p.qscale[r16] * p.mult : 0.f;
+    const float qc = (r16 < p.nq && p.qconst) ? p.qconst[r16] : 0.f;
+    const int nkb = p.dim >> 5;
+    const int kb0 = (nkb * wave) >> 2, kb1 = (nkb * (wave + 1)) >> 2;       // this wave's K blocks
+    const _Float16* qrow = sQ + min(r16, p.nq - 1) * qld + 8 * g;
+    int par = 0;
+    for (int64_t row0 = w_begin; row0 < w_end; row0 += 16, par ^= 1) {
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        const int64_t ra = min(row0 + r16, p.n - 1);
+        const _Float16* pa = p.db + ra * p.dim + 8 * g;
+        constexpr int PKB = 16;
+        for (int kp = kb0; kp < kb1; kp += PKB) {
+            const int nb = min(PKB, kb1 - kp);
+            f16x8 v[PKB];
+#pragma unroll
+            for (int kb = 0; kb < PKB; ++kb)
+                if (kb < nb) v[kb] = *reinterpret_cast<const f16x8*>(pa + (kp + kb) * 32);
+#pragma unroll
+            for (int kb = 0; kb < PKB; ++kb)
+                if (kb < nb) {
+                    const f16x8 b = *reinterpret_cast<const f16x8*>(qrow + (kp + kb) * 32);
+                    if (kb & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[kb], b, acc1, 0, 0, 0);
+                    else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v[kb], b, acc0, 0, 0, 0);
+                }
+        }
+        f32x4 sum = acc0 + acc1;
+        if (wave > 0) sPart[(par * 3 + wave - 1) * 64 + lane] = sum;
+        __syncthreads();                 // (one barrier per step: the partial buffers alternate, so step t + 1's writes cannot
+                                         // overtake wave 0's reads of step t)
+        if (wave == 0) {
+            sum = ((sum + sPart[(par * 3 + 0) * 64 + lane]) + sPart[(par * 3 + 1) * 64 + lane]) + sPart[(par * 3 + 2) * 64 + lane];
+            bool any = false;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = row0 + 4 * g + e;
+                const int64_t rc = min(row, p.n - 1);
+                const float rs = p.rscale ? p.rscale[rc] : p.uscale;
+                const float yn = p.rbias ? p.bias_sign * p.rbias[rc] + qc : qc;
+                const float sc = fmaf(sum[e] * rs, qs, yn);
+                if (row < w_end && r16 < p.nq && sc >= thr) {
+                    const int sl = atomicAdd(&sCnt[r16], 1);
+                    sCand[r16 * SQ_SLOTS + sl] = make_float2(sc, __int_as_float((int)row));
+                    any = true;
+                }
+            }
+            if (__any(any)) {
+                if (lane < SQ_NQ) {
+                    const int c = sCnt[lane];
+                    for (int i = 0; i < c; ++i) {
+                        const float2 cv = sCand[lane * SQ_SLOTS + i];
+                        list_insert<KSEL>(lst, pack_key(cv.x, __float_as_int(cv.y)));
+                    }
+                    sCnt[lane] = 0;
+                }
+                thr = __shfl(key_score(lst[KSEL - 1]), r16, 64);
+            }
+        }
+    }
+    if (wave == 0 && lane < p.nq) {
+        float* ls = p.part_score + ((int64_t)lane * p.n_parts + blockIdx.x) * p.k;
+        int* li = p.part_idx + ((int64_t)lane * p.n_parts + blockIdx.x) * p.k;
+#pragma unroll
+        for (int j = 0; j < KSEL; ++j)
+            if (j < p.k) { ls[j] = key_score(lst[j]); li[j] = key_id(lst[j]); }
+    }
+}
+
 constexpr size_t knn_reg_lds_bytes() { return 4 * KD_TILE_BYTES + sizeof(float2) * KT_N * CAND_CAP + sizeof(float) * KT_N + sizeof(int) * KT_N + 16; }
 
 // ---- merge of sorted partial lists -----------------------------------------------------------------------
@@ -967,6 +1065,7 @@ struct RefineParams {
 constexpr int RF_THREADS = 256;
 constexpr int RF_MAXL = 4;               // lists per thread: n_parts <= 1024
 constexpr int RF_STAGE_MAX = 6144;       // list entries per query that k_merge_refine<true> stages in LDS (48 KB + candidates)
+constexpr int RF_STAGE_MAX_SMALLQ = 16384;   // ... for batches of <= 16 queries (128 KB: occupancy does not matter there)
 
 constexpr size_t refine_lds_bytes(int cap) { return (size_t)cap * 20 + 256; }      // candidates + per-wave scratch of k_merge_refine
 
@@ -2001,7 +2100,11 @@ __global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ rows, 
     float mx = 0.f;
     for (int i = lane; i < dim; i += 64) mx = fmaxf(mx, fabsf(rows[row * dim + i] - (mu ? mu[i] : 0.f)));
     mx = wave_max(mx);
-    if (lane == 0) { atomicMax(&out[0], __float_as_uint(mx)); atomicMin(&out[1], __float_as_uint(mx)); }
+    if (lane == 0) {        // (atomics only when the row moves an extreme it can see: same-address atomics serialise)
+        const unsigned u = __float_as_uint(mx);
+        if (u > *reinterpret_cast<volatile unsigned*>(&out[0])) atomicMax(&out[0], u);
+        if (u < *reinterpret_cast<volatile unsigned*>(&out[1])) atomicMin(&out[1], u);
+    }
 }
 
 static void knn_drop_plane(radad_knn_t h) {
@@ -2391,14 +2494,23 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     }
     const bool smallq = smallq_geom && !smallq_hi && !h->f16 && h->dim % 32 == 0 && sq_lds_f32 <= SQ_LDS_BUDGET;
     int sq_rows_per_wave = 0;
-    if (smallq || smallq_hi) {
+    // a small store of wide rows (the reference's own: 25 423 x 5376) has too few 16-row steps to occupy the chip with one wave per
+    // row slice: the K-split form puts four waves on every step
+    const bool sq_ksplit = smallq_hi && h->dim >= 1024 && ceil_div64(h->ntotal, 16) < 4096;
+    if (sq_ksplit) {
+        int64_t rpg = 16;
+        while (ceil_div64(h->ntotal, rpg) * ksel > RF_STAGE_MAX_SMALLQ) rpg += 16;
+        sq_rows_per_wave = (int)rpg;                  // (rows per WORKGROUP in this form)
+        n_splits = (int)ceil_div64(h->ntotal, rpg);
+        n_qtiles = 1;
+    } else if (smallq || smallq_hi) {
         // a wave streams >= 128 KB (128 rows at dim 512) so that its lists' hand-over stays small beside the stream, but no more
         // rows than leave 8 waves for every CU; the lists of a query (one per workgroup) should fit the re-rank's staged form
         const int64_t waves_wanted = 256 * 8;
         const size_t rb = smallq_hi ? (size_t)h->dim * 2 : (size_t)h->dim * 4;
         const int64_t rows_min = std::max<int64_t>(16, std::min<int64_t>(128, ceil_div64(ceil_div64(128 * 1024, (int64_t)rb), 16) * 16));
         int64_t rpw = std::max<int64_t>(ceil_div64(ceil_div64(h->ntotal, waves_wanted), 16) * 16, rows_min);
-        while (rpw < 128 && ceil_div64(ceil_div64(h->ntotal, rpw), 4) * ksel > RF_STAGE_MAX) rpw += 16;
+        while (rpw < 128 && ceil_div64(ceil_div64(h->ntotal, rpw), 4) * ksel > RF_STAGE_MAX_SMALLQ) rpw += 16;
         sq_rows_per_wave = (int)rpw;
         n_splits = (int)ceil_div64(ceil_div64(h->ntotal, rpw), 4);                // workgroups of 4 waves = lists per query
         n_qtiles = 1;
@@ -2608,7 +2720,14 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         sp.rows_per_wave = sq_rows_per_wave; sp.n_parts = n_splits; sp.part_score = ps; sp.part_idx = pi;
         const size_t lds = sq_lds_hi;
         const dim3 sgrid((unsigned)n_splits);
-        if (ksel <= 16) {
+        if (sq_ksplit) {
+            const void* fn = ksel <= 16 ? reinterpret_cast<const void*>(k_knn_hi_smallq_ksplit<16>) : reinterpret_cast<const void*>(k_knn_hi_smallq_ksplit<32>);
+            RADAD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            h->prof.begin(st);
+            if (ksel <= 16) hipLaunchKernelGGL(k_knn_hi_smallq_ksplit<16>, sgrid, dim3(SQ_THREADS), lds, st, sp);
+            else hipLaunchKernelGGL(k_knn_hi_smallq_ksplit<32>, sgrid, dim3(SQ_THREADS), lds, st, sp);
+            h->prof.end(st);
+        } else if (ksel <= 16) {
             RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_hi_smallq<16>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             h->prof.begin(st);
@@ -2716,8 +2835,12 @@ static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* glo
     {   // certified mode with lists that fit the LDS: selection on a staged copy (one round of loads instead of a pointer chase)
         const size_t entries = (size_t)m.n_parts * m.part_len;
         RADAD_REQUIRE(!c.emit || (m.eps && entries <= (size_t)RF_STAGE_MAX), "radad_knn_search: candidate buffer larger than the re-rank stages");
-        if (m.eps && entries <= (size_t)RF_STAGE_MAX)
-            hipLaunchKernelGGL(k_merge_refine<true>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(c.cap) + entries * 8 + 1024, st, m);
+        if (m.eps && entries <= (size_t)(nq <= SQ_NQ ? RF_STAGE_MAX_SMALLQ : RF_STAGE_MAX)) {
+            const size_t rlds = refine_lds_bytes(c.cap) + entries * 8 + 1024;
+            if (rlds > 48 * 1024)
+                RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_merge_refine<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rlds));
+            hipLaunchKernelGGL(k_merge_refine<true>, dim3((unsigned)nq), dim3(RF_THREADS), rlds, st, m);
+        }
         else
             hipLaunchKernelGGL(k_merge_refine<false>, dim3((unsigned)nq), dim3(RF_THREADS), refine_lds_bytes(c.cap), st, m);
     }
