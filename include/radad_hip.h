@@ -195,7 +195,8 @@ int radad_filter_topk(const float* in_dist_dev, const int64_t* in_idx_dev, int64
 /* ------------------------------------------------------------------------------------------------
  * Inverted-file flat index: faiss.IndexIVFFlat(IndexFlatL2 quantiser, d, nlist, METRIC_L2), the reference's optional
  * `vector_db_index_type == "IVF"` (vector_database.py:65-70 create with nlist = max(64, ivf_nlist), :124-128 train on the
- * first <= 50 000 rows, :174-179 nprobe = config.vector_db_nprobe).  dim must be a multiple of 32, k <= 26.
+ * first <= 50 000 rows, :174-179 nprobe = config.vector_db_nprobe).  dim must be a multiple of 32, k <= 128: up to k = 26 the
+ * probed lists are scanned; 27..128 is answered by the exact certified scan of the same rows (recall 1.0).
  * A search returns the exact top-k (squared L2, ties to the lower id) among the rows of the nprobe lists whose
  * centroids are nearest to the query; -1 / +inf where those lists hold fewer than k rows.
  * ---------------------------------------------------------------------------------------------- */

@@ -9,7 +9,8 @@ What callers of the reference rely on and still find here:
     used at vector_database.py:124,138,151,169,181 and pipeline.py:465,503).
 Index types: 'L2' -> squared-L2 ascending; 'IP' -> inner product descending, with rows and queries
 L2-normalised first when config.normalize_for_ip (default True) i.e. cosine (vector_database.py:61-64,97,100-105).
-'IVF' (vector_database.py:65-70) -> HipIVFFlatIndex (k-means coarse quantiser + list scan, csrc/ivf.inc; k <= 26).
+'IVF' (vector_database.py:65-70) -> HipIVFFlatIndex (k-means coarse quantiser + list scan, csrc/ivf.inc; k <= 128: above 26 the exact scan
+of the same rows answers).
 Device-resident variants (`search_device`, `reconstruct_batch`) let the pipeline skip the D2H/H2D hops.
 """
 import ctypes as C
@@ -362,7 +363,8 @@ class HipIVFFlatIndex:
 
     add_device = add
 
-    MAX_K = 26      # csrc/ivf.inc: k + 6 candidates per (query, list) in 32-entry register lists
+    MAX_K = 128     # csrc/ivf.inc: up to k = 26 the probed lists are scanned (k + 6 candidates per (query, list) in 32-entry register
+                    # lists); 27..128 is answered by the exact certified scan of the same rows (recall 1.0, the flat scan's cost)
 
     def search_device(self, q, k: int):
         import torch

@@ -98,3 +98,23 @@ def test_vector_database_ivf_mode(gpu, tmp_path):
     np.testing.assert_array_equal(v2.index.assignments(), vdb.index.assignments())
     for i in (0, 1, 5999, 11999):
         np.testing.assert_array_equal(v2.index.reconstruct(i), db[i])
+
+
+@pytest.mark.parametrize("k", [40, 100])
+def test_ivf_large_k_is_answered_by_the_exact_scan(gpu, k):
+    """faiss takes k up to 2048 (vector_database.py:169-181).  The list scan holds k + 6 <= 32 candidates per (query, list); above
+    k = 26 the index answers with the exact search over the same rows (ids in insertion order): the float64 brute force itself"""
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    n, dim, nlist, nq = 30000, 128, 64, 50
+    db = _clustered(n, dim, 50, 5101)
+    q = _clustered(nq, dim, 50, 5103)
+    idx = R.HipIVFFlatIndex(dim, nlist, gpu.index or 0)
+    idx.train(db[:10000])
+    idx.add(db)
+    idx.nprobe = 4
+    D, I = idx.search(q, k)
+    od, oi = O.knn(db, q, k, "L2")
+    np.testing.assert_array_equal(I, oi)
+    np.testing.assert_allclose(D, od, rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        idx.search(q, 129)
