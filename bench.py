@@ -327,6 +327,7 @@ def main():
     rechecked = launch["rechecked_queries"]
     n_launch = max(1, launch.get("scan_launches", 1))       # the tile scan covers a large store in several launches: one entry each
     shard_ms = searcher.timings() if world > 1 else []
+    searcher.timing = False                                   # (the legs below are not broken down: no events to create)
 
     # ---- sustained: the same step, looped for >= args.sustain seconds (the chip settles at its steady-state clock) ------
     sustained = None
