@@ -253,7 +253,7 @@ def main():
             _, ids, key64 = vdb.index.search_finish(lb, return_f64=True)
             return key64, ids
         bounded = (vdb.index.search_begin, _finish)
-    searcher = ShardedSearch(local_search, vdb.index.metric, bounded=bounded, timing=(world > 1 and not rehearse))
+    searcher = ShardedSearch(local_search, vdb.index.metric, bounded=bounded, timing=world > 1)
 
     def barrier():
         if world > 1:
