@@ -1164,6 +1164,23 @@ __global__ __launch_bounds__(RF_THREADS) void k_kth_floor(KthParams p) {
     }
 }
 
+// the scan's first admission floor: the rank-th best of the sample pre-pass's entries (n_ent per query, unsorted; a sentinel
+// index = no entry), lowered by 2 eps -- a_k over the WHOLE store is >= the rank-th best of any subset for rank >= k, so the
+// floor is <= tau = a_k - 2 eps always.  -inf when the sample holds fewer entries.  One workgroup per query (k_thr_from_parts, its
+// predecessor, walked the 512 list heads `rank` times with a wave: 19 us against 6).
+__global__ __launch_bounds__(RF_THREADS) void k_floor_from_sample(const float* __restrict__ score, const int* __restrict__ idx, int n_ent, int rank,
+                                                                 const float* __restrict__ eps, float* __restrict__ thr) {
+    extern __shared__ __attribute__((aligned(16))) char smem_f[];
+    float* e_sc = reinterpret_cast<float*>(smem_f);                      // [n_ent]
+    int* hist = reinterpret_cast<int*>(e_sc + n_ent);                    // [256]
+    int* xchg = hist + 256;
+    const int64_t q = blockIdx.x;
+    for (int i = threadIdx.x; i < n_ent; i += RF_THREADS)
+        e_sc[i] = idx[q * n_ent + i] != IDX_SENTINEL ? score[q * n_ent + i] : -INFINITY;
+    const float a = radix_select_kth(e_sc, n_ent, rank, hist, xchg);
+    if (threadIdx.x == 0) thr[q] = a > -INFINITY ? a - 2.f * eps[q] : -INFINITY;
+}
+
 template <bool STAGED>
 __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
@@ -2474,7 +2491,6 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         // the sample pre-pass: one tile per workgroup, at most KW_SAMPLE_SPLITS tiles and 1/8 of the store (whatever the number of
         // query tiles: every phase of the scan is sized from the sample, a small sample means more phases)
         s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
-        static_assert(KW_SAMPLE_SPLITS * 8 <= 64 * THR_LISTS_PER_LANE, "k_thr_from_parts: lists per lane");
         if (s_splits >= 8 && s_splits * KW_SAMPLE_LIST >= 2 * ksel) {
             if (h->hi_skip > 0) { --h->hi_skip; skipped_hi = true; }
             else if (knn_ensure_hi(h, st, true)) { use_hi = true; n_qtiles = wq; }
@@ -2660,8 +2676,9 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             else if (rsc == 1) hipLaunchKernelGGL(k_knn_hi_sample<1>, sg, sb, lds, st, sp);
             else if (rsc == 2) hipLaunchKernelGGL(k_knn_hi_sample<2>, sg, sb, lds, st, sp);
             else hipLaunchKernelGGL(k_knn_hi_sample<3>, sg, sb, lds, st, sp);
-            hipLaunchKernelGGL(k_thr_from_parts, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, ps, pi, sp.n_splits * 8, 2,
-                               k + margin, nq, thr_init, (const float*)eps);
+            const int n_ent = sp.n_splits * KW_SAMPLE_LIST;
+            hipLaunchKernelGGL(k_floor_from_sample, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)n_ent * 4 + 1040, st, (const float*)ps,
+                               (const int*)pi, n_ent, k + margin, (const float*)eps, thr_init);
             wp.thr_init = thr_init;
         }
         const dim3 b(KW_THREADS);
