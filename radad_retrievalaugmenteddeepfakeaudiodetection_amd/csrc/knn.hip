@@ -915,7 +915,7 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams 
 // each for the SAME 16 rows, so every 16-row step keeps 4 waves busy (6 356 wave-steps over the store); their partial products
 // meet in LDS, are added in a fixed order (deterministic) by wave 0, which also keeps the workgroup's top-k lists.
 template <int KSEL>
-__global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq_ksplit(SmallQHiParams p) {
+__global__ __launch_bounds__(SQ_THREADS, KSEL <= 16 ? 4 : 2) void k_knn_hi_smallq_ksplit(SmallQHiParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int qld = p.dim + 8;
     _Float16* sQ = reinterpret_cast<_Float16*>(smem);             // [nq][dim + 8]
@@ -2513,9 +2513,13 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     // a small store of wide rows (the reference's own: 25 423 x 5376) has too few 16-row steps to occupy the chip with one wave per
     // row slice: the K-split form puts four waves on every step
     const bool sq_ksplit = smallq_hi && h->dim >= 1024 && ceil_div64(h->ntotal, 16) < 4096;
+    // (its lists are 16 entries for k <= 16 -- the reference's k = 15 included -- instead of k + 6 <= 32: half the list registers,
+    // twice the waves per SIMD to hide the HBM latency behind.  A workgroup whose 16-entry list is used up by rows within the
+    // threshold rejects the query; the exact kernel over so small a store costs ~0.3 ms)
+    const int ksel_sq = (sq_ksplit && k <= 16) ? 16 : ksel;
     if (sq_ksplit) {
         int64_t rpg = 16;
-        while (ceil_div64(h->ntotal, rpg) * ksel > RF_STAGE_MAX_SMALLQ) rpg += 16;
+        while (ceil_div64(h->ntotal, rpg) * ksel_sq > RF_STAGE_MAX_SMALLQ) rpg += 16;
         sq_rows_per_wave = (int)rpg;                  // (rows per WORKGROUP in this form)
         n_splits = (int)ceil_div64(h->ntotal, rpg);
         n_qtiles = 1;
@@ -2542,7 +2546,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     h->last_threads = use_hi ? KW_THREADS : ((smallq || smallq_hi) ? SQ_THREADS : KNN_THREADS);
     h->last_kind = use_hi ? RADAD_SCAN_HI_TILE : smallq_hi ? RADAD_SCAN_HI_SMALLQ : smallq ? RADAD_SCAN_F32_SMALLQ
                           : f16_tile ? RADAD_SCAN_F16_TILE : RADAD_SCAN_F32_TILE;
-    const int plen = use_hi ? emit_cap : ksel;   // entries of a partial list / of the candidate buffer
+    const int plen = use_hi ? emit_cap : ksel_sq;   // entries of a partial list / of the candidate buffer
     const int n_parts = use_hi ? 1 : n_splits;
     const int cap = cert ? std::max(k + KNN_CERT_EXTRA, KNN_CERT_CAP) : ksel;
     const int xgroup = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(64 * 1024) / ((size_t)h->dim * 4)));
@@ -2733,15 +2737,15 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         sp.uscale = h->f16 ? 1.0f : (h->uniform_e != HI_E_PER_ROW ? ldexpf(1.0f, -h->uniform_e) : (h->metric == RADAD_METRIC_COSINE ? 0x1p-14f : 1.0f));
         sp.rbias = biased ? (mu ? h->rbias : h->ynorm) : nullptr; sp.bias_sign = l2 ? -1.f : 1.f; sp.mult = l2 ? 2.f : 1.f;
         sp.qconst = biased ? qconst : nullptr;
-        sp.q = qh; sp.qscale = qscale; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel;
+        sp.q = qh; sp.qscale = qscale; sp.n = h->ntotal; sp.nq = (int)nq; sp.dim = h->dim; sp.k = ksel_sq;
         sp.rows_per_wave = sq_rows_per_wave; sp.n_parts = n_splits; sp.part_score = ps; sp.part_idx = pi;
         const size_t lds = sq_lds_hi;
         const dim3 sgrid((unsigned)n_splits);
         if (sq_ksplit) {
-            const void* fn = ksel <= 16 ? reinterpret_cast<const void*>(k_knn_hi_smallq_ksplit<16>) : reinterpret_cast<const void*>(k_knn_hi_smallq_ksplit<32>);
+            const void* fn = ksel_sq <= 16 ? reinterpret_cast<const void*>(k_knn_hi_smallq_ksplit<16>) : reinterpret_cast<const void*>(k_knn_hi_smallq_ksplit<32>);
             RADAD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             h->prof.begin(st);
-            if (ksel <= 16) hipLaunchKernelGGL(k_knn_hi_smallq_ksplit<16>, sgrid, dim3(SQ_THREADS), lds, st, sp);
+            if (ksel_sq <= 16) hipLaunchKernelGGL(k_knn_hi_smallq_ksplit<16>, sgrid, dim3(SQ_THREADS), lds, st, sp);
             else hipLaunchKernelGGL(k_knn_hi_smallq_ksplit<32>, sgrid, dim3(SQ_THREADS), lds, st, sp);
             h->prof.end(st);
         } else if (ksel <= 16) {
