@@ -805,7 +805,7 @@ struct SmallQHiParams {
 };
 
 template <int KSEL>
-__global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams p) {
+__global__ __launch_bounds__(SQ_THREADS, KSEL <= 16 ? 4 : 2) void k_knn_hi_smallq(SmallQHiParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int qld = p.dim + 8;                                    // padded query row (halfs): 16-byte chunks of the 16 rows fall in distinct banks
     _Float16* sQ = reinterpret_cast<_Float16*>(smem);             // [nq][dim + 8]
