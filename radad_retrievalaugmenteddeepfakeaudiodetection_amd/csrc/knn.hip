@@ -804,8 +804,9 @@ struct SmallQHiParams {
     float* part_score; int* part_idx;   // [nq, n_parts, k]
 };
 
+// (launch bounds: 155 VGPRs = 3 waves per SIMD for KSEL 16; forcing 4 (128 VGPRs) spills the 16-load panel: 0.41 instead of 0.21 ms)
 template <int KSEL>
-__global__ __launch_bounds__(SQ_THREADS, KSEL <= 16 ? 4 : 2) void k_knn_hi_smallq(SmallQHiParams p) {
+__global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int qld = p.dim + 8;                                    // padded query row (halfs): 16-byte chunks of the 16 rows fall in distinct banks
     _Float16* sQ = reinterpret_cast<_Float16*>(smem);             // [nq][dim + 8]
