@@ -916,7 +916,7 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams 
 // each for the SAME 16 rows, so every 16-row step keeps 4 waves busy (6 356 wave-steps over the store); their partial products
 // meet in LDS, are added in a fixed order (deterministic) by wave 0, which also keeps the workgroup's top-k lists.
 template <int KSEL>
-__global__ __launch_bounds__(SQ_THREADS, KSEL <= 16 ? 4 : 2) void k_knn_hi_smallq_ksplit(SmallQHiParams p) {
+__global__ __launch_bounds__(SQ_THREADS, KSEL <= 16 ? 3 : 2) void k_knn_hi_smallq_ksplit(SmallQHiParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int qld = p.dim + 8;
     _Float16* sQ = reinterpret_cast<_Float16*>(smem);             // [nq][dim + 8]
