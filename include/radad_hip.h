@@ -220,9 +220,11 @@ int radad_ivf_search(radad_ivf_t h, const float* q_dev, int64_t nq, int k, int n
                                                                     synchronously */
 int radad_ivf_reconstruct(radad_ivf_t h, const int64_t* idx_dev, int64_t n, float* out_dev, void* stream);
 
-/* out[r] = the k-th largest of in[r][0..m) (1 <= k <= m <= 1280; NaN ranks lowest).  For the sharded search: m = G k lower bounds per
- * query gathered from G shards' radad_knn_search_begin -> the bound radad_knn_search_finish takes. */
-int radad_kth_largest(const float* in_dev, int64_t n, int m, int k, float* out_dev, int device, void* stream);
+/* out[r] = the k-th largest of the groups x per_group values of row r, value (g, i) at in[(g n + r) per_group + i] -- the layout
+ * [groups][n][per_group] an all-gather of the shards' [n][k] bound blocks has (groups = 1: plain [n][m]); groups x per_group <= 1280,
+ * 1 <= k <= groups x per_group; NaN ranks lowest.  For the sharded search: the G k lower bounds per query gathered from G
+ * shards' radad_knn_search_begin -> the bound radad_knn_search_finish takes. */
+int radad_kth_largest(const float* in_dev, int64_t n, int groups, int per_group, int k, float* out_dev, int device, void* stream);
 /* row L2 normalisation x / (|x| + 1e-12)  (vector_database.py:100-105); in-place allowed */
 int radad_rownorm(const float* in_dev, float* out_dev, int64_t n, int dim, int device, void* stream);
 

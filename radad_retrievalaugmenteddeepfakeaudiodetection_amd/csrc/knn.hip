@@ -1043,6 +1043,7 @@ struct RefineParams {
     const int* qflag;         // optional [nq]: the scan dropped a candidate of this query
     const int* part_cnt;      // optional [nq] (emit-mode scan, n_parts == 1): entries filled in the query's buffer; > part_len = overflow
     const float* global_lb;   // optional [nq] (sharded search): the best lower bound any shard has of the exact k-th best score
+    const float* ak_in;       // optional [nq] (emit-mode scan, two-half search): a_k as k_kth_floor found it for the bounds
     int* flag_count;          // certified mode: [1] number of uncertified queries (atomicAdd) ...
     int* flag_sel;            // ... and their indices, in arrival order
     int* stats;               // optional [5]: sum of candidates re-scored, queries rejected for: buffer full / list used up /
@@ -1137,6 +1138,7 @@ struct KthParams {
     const float* eps;          // [nq]
     float* floor_io;
     float* lb_out;
+    float* ak_out;             // optional [nq]: a_k itself (the re-rank of a two-half search takes it instead of selecting again)
 };
 __global__ __launch_bounds__(RF_THREADS) void k_kth_floor(KthParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_k[];
@@ -1149,6 +1151,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_kth_floor(KthParams p) {
     for (int i = threadIdx.x; i < NE; i += RF_THREADS) e_sc[i] = p.score[q * p.cap + i];
     const float a_k = radix_select_kth(e_sc, NE, p.k, hist, xchg);
     const float e = p.eps[q];
+    if (threadIdx.x == 0 && p.ak_out) p.ak_out[q] = a_k;
     if (threadIdx.x == 0 && p.floor_io && a_k > -INFINITY) p.floor_io[q] = fmaxf(p.floor_io[q], a_k - 2.f * e);
     if (p.lb_out) {
         float* out = p.lb_out + q * p.k;
@@ -1221,7 +1224,9 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     // the k best among them; the first version found the k best one by one, k rounds of a block-wide arg-max with two barriers
     // each: 40 % of this kernel)
     {
-        const float a_k = radix_select_kth(e_sc, NE, p.k, hist, w_pt);
+        float a_k;
+        if (p.ak_in) { a_k = p.ak_in[q]; __syncthreads(); }             // (the barrier publishes e_sc, as the select's would)
+        else a_k = radix_select_kth(e_sc, NE, p.k, hist, w_pt);
         if (a_k > -INFINITY) tau = a_k - two_eps;                        // (fewer than k listed rows: tau stays -inf, all of them go on)
     }
     // sharded search: no row whose score is below (the best lower bound any shard has of the exact k-th best) - eps can be in the
@@ -1907,15 +1912,19 @@ __global__ __launch_bounds__(256) void k_filter_topk(const float* __restrict__ i
 // out[r] = the k-th largest of in[r][0..m) (NaN ranks lowest).  One wave per row, a lane holds up to KTH_PER_LANE values; k - 1 rounds
 // of "wave-wide maximum, its first holder drops it".  The sharded search's bound: m = G k lower bounds per query.
 constexpr int KTH_PER_LANE = 20;         // m <= 1280 (8 shards x k = 128, or 40 x 32)
-__global__ __launch_bounds__(256) void k_kth_largest(const float* __restrict__ in, int64_t n, int m, int k, float* __restrict__ out) {
+// Value j = g per_group + i of row r sits at in[(g n + r) per_group + i]: [groups][n][per_group], the layout an all-gather of the
+// shards' [n][k] bound blocks produces (groups = 1: plain [n][m]).
+__global__ __launch_bounds__(256) void k_kth_largest(const float* __restrict__ in, int64_t n, int groups, int per_group, int k,
+                                                     float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n) return;
+    const int m = groups * per_group;
     float v[KTH_PER_LANE];
 #pragma unroll
     for (int i = 0; i < KTH_PER_LANE; ++i) {
         const int c = lane + 64 * i;
-        const float x = c < m ? in[r * m + c] : -INFINITY;
+        const float x = c < m ? in[((int64_t)(c / per_group) * n + r) * per_group + c % per_group] : -INFINITY;
         v[i] = x == x ? x : -INFINITY;
     }
     float best = -INFINITY;
@@ -1969,6 +1978,8 @@ struct SearchCtx {
     bool canonical = false;            // the scan's scores estimate q.y / -|q - y|^2 themselves (comparable across shards); the fp32
                                        // kernels' L2 score 2 q.y - |y|^2 lacks the -|q|^2: a cross-shard bound does not apply to it
     const float* q_use = nullptr;       // fp32 queries as the re-rank reads them (caller's buffer, or the workspace's normalised copy)
+    bool have_ak = false;              // k_kth_floor left a_k in the workspace (o_ak)
+    size_t o_ak = 0;
     size_t o_eps = 0, o_thr = 0, o_cnt = 0, o_fcount = 0, o_fsel = 0, o_ps = 0, o_pi = 0, o_xk = 0, o_xi = 0;
 };
 
@@ -2571,6 +2582,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     const size_t o_qconst = off; off += b_vec;
     const size_t o_eps = off; off += b_vec;
     const size_t o_thr = off; off += b_vec;
+    const size_t o_ak = off; off += b_vec;             // a_k of the candidates (two-half searches: k_kth_floor -> k_merge_refine)
     const size_t o_cnt = off; off += b_vec;            // cand_cnt [nq] int (zeroed by k_hi_rows with the counters)
     const size_t o_fcount = off; off += 256;           // flag_count + statistics
     const size_t o_fsel = off; off += b_vec;
@@ -2589,6 +2601,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     float* qconst = (float*)(ws + o_qconst);
     float* eps = (float*)(ws + o_eps);
     float* thr_init = (float*)(ws + o_thr);
+    float* qconst_ak = (float*)(ws + o_ak);
     int* cand_cnt = (int*)(ws + o_cnt);
     int* flag_count = (int*)(ws + o_fcount);
     float* ps = (float*)(ws + o_ps);
@@ -2716,7 +2729,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             if (r0 == 0 && (int64_t)ksel * h->ntotal <= (int64_t)(emit_cap / 3) * s_splits * KW_M) r1 = h->ntotal;
             if (r0 > 0) {
                 KthParams kp;
-                kp.score = ps; kp.cnt = cand_cnt; kp.cap = emit_cap; kp.k = k; kp.eps = eps; kp.floor_io = thr_init; kp.lb_out = nullptr;
+                kp.score = ps; kp.cnt = cand_cnt; kp.cap = emit_cap; kp.k = k; kp.eps = eps; kp.floor_io = thr_init; kp.lb_out = nullptr; kp.ak_out = nullptr;
                 hipLaunchKernelGGL(k_kth_floor, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)emit_cap * 4 + 1040, st, kp);
             }
             launch_range(r0, r1);
@@ -2815,6 +2828,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         if (use_hi && cert) {
             KthParams kp;
             kp.score = ps; kp.cnt = cand_cnt; kp.cap = emit_cap; kp.k = k; kp.eps = eps; kp.floor_io = nullptr; kp.lb_out = lb_out;
+            kp.ak_out = qconst_ak;
             hipLaunchKernelGGL(k_kth_floor, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)emit_cap * 4 + 1040, st, kp);
         } else {
             hipLaunchKernelGGL(k_fill_f32, dim3((unsigned)ceil_div64(nq * k, 256)), dim3(256), 0, st, lb_out, nq * k, -INFINITY);
@@ -2826,6 +2840,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     ctx->nq = nq; ctx->k = k; ctx->l2 = l2; ctx->cslot = cslot; ctx->n_parts = n_parts; ctx->plen = plen; ctx->cap = cap; ctx->xgroup = xgroup;
     ctx->cert = cert; ctx->emit = use_hi; ctx->use_floor = use_hi; ctx->q_use = q_use;
     ctx->canonical = use_hi || smallq_hi || !l2;
+    ctx->have_ak = lb_out != nullptr && use_hi && cert; ctx->o_ak = o_ak;
     ctx->o_eps = o_eps; ctx->o_thr = o_thr; ctx->o_cnt = o_cnt; ctx->o_fcount = o_fcount; ctx->o_fsel = o_fsel; ctx->o_ps = o_ps; ctx->o_pi = o_pi;
     ctx->o_xk = o_xk; ctx->o_xi = o_xi;
     return RADAD_OK;
@@ -2844,6 +2859,7 @@ static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* glo
     m.part_len = c.plen; m.cap = c.cap;
     m.eps = c.cert ? (const float*)(ws + c.o_eps) : nullptr; m.thr_init = c.use_floor ? (const float*)(ws + c.o_thr) : nullptr; m.qflag = nullptr;
     m.part_cnt = c.emit ? (const int*)(ws + c.o_cnt) : nullptr; m.global_lb = (c.cert && c.canonical) ? global_lb : nullptr;
+    m.ak_in = c.have_ak ? (const float*)(ws + c.o_ak) : nullptr;
     m.flag_count = flag_count; m.flag_sel = flag_sel;
     m.db = h->rows; m.db_f16 = h->f16; m.q = c.q_use; m.id_map = nullptr; m.id_base = h->id_base; m.out_dist = out_dist_dev; m.out_idx = out_idx_dev;
     m.out_key = out_key_dev;
@@ -3296,12 +3312,13 @@ int radad_filter_topk(const float* in_dist_dev, const int64_t* in_idx_dev, int64
     return RADAD_OK;
 }
 
-int radad_kth_largest(const float* in_dev, int64_t n, int m, int k, float* out_dev, int device, void* stream) {
-    RADAD_REQUIRE(n >= 0 && m >= 1 && m <= 64 * KTH_PER_LANE && k >= 1 && k <= m, "radad_kth_largest: bad shape (m <= %d, 1 <= k <= m)", 64 * KTH_PER_LANE);
+int radad_kth_largest(const float* in_dev, int64_t n, int groups, int per_group, int k, float* out_dev, int device, void* stream) {
+    RADAD_REQUIRE(n >= 0 && groups >= 1 && per_group >= 1 && (int64_t)groups * per_group <= 64 * KTH_PER_LANE && k >= 1 && k <= groups * per_group,
+                  "radad_kth_largest: bad shape (groups x per_group <= %d, 1 <= k <= groups x per_group)", 64 * KTH_PER_LANE);
     if (n == 0) return RADAD_OK;
     RADAD_REQUIRE(in_dev && out_dev, "radad_kth_largest: NULL buffer");
     DeviceGuard g(device);
-    hipLaunchKernelGGL(k_kth_largest, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, (hipStream_t)stream, in_dev, n, m, k, out_dev);
+    hipLaunchKernelGGL(k_kth_largest, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, (hipStream_t)stream, in_dev, n, groups, per_group, k, out_dev);
     RADAD_HIP_CHECK(hipGetLastError());
     return RADAD_OK;
 }

@@ -182,10 +182,10 @@ class HipFlatIndex:
         bound of the exact k-th best score over all shards"""
         import torch
         G, nq, kk = lb_all.shape
-        flat = lb_all.permute(1, 0, 2).reshape(nq, G * kk).contiguous().float()
+        flat = lb_all.contiguous().float()                 # [G][nq][k] as gathered: the kernel reads that layout
         out = torch.empty((nq,), device=flat.device, dtype=torch.float32)
         with torch.cuda.device(flat.device):
-            _lib.check(_lib.load().radad_kth_largest(flat.data_ptr(), nq, G * kk, int(k), out.data_ptr(), flat.device.index,
+            _lib.check(_lib.load().radad_kth_largest(flat.data_ptr(), nq, G, kk, int(k), out.data_ptr(), flat.device.index,
                                                      _lib.stream_ptr(flat.device)), "radad_kth_largest")
         return out
 
