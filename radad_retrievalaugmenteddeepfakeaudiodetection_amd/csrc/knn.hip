@@ -2538,7 +2538,10 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     } else if (smallq || smallq_hi) {
         // a wave streams >= 128 KB (128 rows at dim 512) so that its lists' hand-over stays small beside the stream, but no more
         // rows than leave 8 waves for every CU; the lists of a query (one per workgroup) should fit the re-rank's staged form
-        const int64_t waves_wanted = 256 * 8;
+        // one full round of resident waves: 1024 SIMDs x the waves per SIMD the kernel's registers allow (k_knn_hi_smallq<16>: 155
+        // VGPRs = 3; the 32-entry and fp32 variants: 2).  (Measured: no difference against 2048 waves on the 1 M x 512 store -- 0.2075
+        // vs 0.208 ms, 4.93 TB/s either way: the stream is not limited by the number of waves in flight.)
+        const int64_t waves_wanted = 1024 * ((smallq_hi && ksel <= 16) ? 3 : 2);
         const size_t rb = smallq_hi ? (size_t)h->dim * 2 : (size_t)h->dim * 4;
         const int64_t rows_min = std::max<int64_t>(16, std::min<int64_t>(128, ceil_div64(ceil_div64(128 * 1024, (int64_t)rb), 16) * 16));
         int64_t rpw = std::max<int64_t>(ceil_div64(ceil_div64(h->ntotal, waves_wanted), 16) * 16, rows_min);
