@@ -91,3 +91,70 @@ def test_fuzz_embed(gpu, seed):
         what = dict(seed=seed, case=case, L=L, hop=fe.hop_length, F=F, levels=levels, mode=mode, norm=norm, gain=gain, lens=lens, err=err)
         assert emb.shape == ref.shape and err < 1e-4, what
         assert torch.equal(emb, emb_dev), what
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_fuzz_scan_phases_and_planes(gpu, knn_oracle_lib, seed):
+    """the round-3 machinery of the certified tile scan under random shapes: stores below / at / above the phase boundaries (one
+    launch, two, three), batches of 17 .. 2100 queries (1 .. 9 query tiles: both XCD mappings), k from 1 to 128, rows with and
+    without a common component (centred / un-centred plane) and of one or of many magnitudes (one scale / per-row scales), appends
+    after the plane was built.  Rows are generated on the device; ids against the C oracle on a 24-query sample of the rows AS
+    STORED."""
+    import torch
+    from conftest import c_knn
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(seed)
+
+    def dev_rows(row0, n, dim, sd):
+        t = torch.empty((n, dim), device=gpu, dtype=torch.float32)
+        _lib.check(lib.radad_synth_rows(t.data_ptr(), row0, n, dim, sd, gpu.index or 0, _lib.stream_ptr(gpu)))
+        return t
+
+    for case in range(6):
+        metric = ["L2", "IP", "COSINE"][rng.integers(3)]
+        dim = int(rng.choice([64, 128, 256, 512]))
+        n = int(rng.choice([16384, 20000, 131072, 131072 + 300, 200000, 1_200_000 if dim <= 128 else 400000]))
+        nq = int(rng.choice([17, 255, 256, 257, 1000, 2100]))
+        k = int(rng.choice([1, 10, 15, 26, 27, 64, 128]))
+        common = bool(rng.integers(2))
+        ragged_scale = bool(rng.integers(3) == 0) and metric != "COSINE"
+        rows = dev_rows(0, n, dim, 20000 + 100 * seed + case)
+        q = dev_rows(0, nq, dim, 21000 + 100 * seed + case)
+        if common:
+            base = dev_rows(0, 1, dim, 22000 + case).abs() + 0.5
+            rows = base + 0.3 * rows
+            q = base + 0.3 * q
+        if ragged_scale:
+            rows *= torch.exp2(torch.arange(n, device=gpu) % 19 - 9).float()[:, None]
+        jj = torch.arange(nq, device=gpu)
+        rows[(jj * 131 + 7) % n] = q + 0.03 * dev_rows(0, nq, dim, 23000 + case)       # one planted neighbour per query
+        m = {"L2": _lib.METRIC_L2, "IP": _lib.METRIC_IP, "COSINE": _lib.METRIC_COSINE}[metric]
+        idx = HipFlatIndex(dim, m, gpu.index or 0)
+        cut = int(rng.choice([n, n, n // 2, n - 1000]))
+        idx.add_device(rows[:cut])
+        if cut < n:
+            idx.search_device(q[:64].contiguous(), min(k, 10))                        # builds the plane on the first part
+            idx.add_device(rows[cut:])
+        D, I, K64 = idx.search_device(q, k, return_f64=True)
+        info, plane = idx.last_launch(), idx.plane_info()
+        what = dict(seed=seed, case=case, metric=metric, dim=dim, n=n, nq=nq, k=k, common=common, ragged_scale=ragged_scale, cut=cut,
+                    plane=plane, info=info)
+        assert info["scan_kind"] == "hi_tile", what
+        if not ragged_scale:
+            assert info["certificate"]["rejected"] <= max(1, nq // 50), what
+        assert bool((I[:, 0] == (jj * 131 + 7) % n).all()) or metric == "IP", what     # (raw inner product favours long rows)
+        sample = torch.from_numpy(rng.choice(nq, size=min(24, nq), replace=False)).to(gpu)
+        stored = idx.reconstruct_batch(torch.arange(n, device=gpu)).cpu().numpy()
+        qs = q[sample].contiguous()
+        if metric == "COSINE":
+            qn = torch.empty_like(qs)
+            _lib.check(lib.radad_rownorm(qs.data_ptr(), qn.data_ptr(), qs.shape[0], dim, gpu.index or 0, _lib.stream_ptr(gpu)))
+            qs = qn
+        od, oi = c_knn(knn_oracle_lib, stored, qs.cpu().numpy(), k, "L2" if metric == "L2" else "IP")
+        gaps_ok = O.rank_gaps(od).min() > 0
+        I_s = I[sample].cpu().numpy()
+        if gaps_ok:
+            assert np.array_equal(I_s, oi), what
+        np.testing.assert_allclose(K64[sample].cpu().numpy(), od, rtol=1e-9, atol=1e-9, err_msg=str(what))
+        del idx, rows, stored
