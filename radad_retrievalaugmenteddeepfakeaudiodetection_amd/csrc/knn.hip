@@ -857,7 +857,7 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_hi_smallq(SmallQHiParams 
             f16x8 v[PKB];
 #pragma unroll
             for (int kb = 0; kb < PKB; ++kb)
-                if (kb < nb) v[kb] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(pa + (kp + kb) * 32));
+                if (kb < nb) v[kb] = *reinterpret_cast<const f16x8*>(pa + (kp + kb) * 32);
 #pragma unroll
             for (int kb = 0; kb < PKB; ++kb)
                 if (kb < nb) {
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(SQ_THREADS, KSEL <= 16 ? 3 : 2) void k_knn_hi_small
             f16x8 v[PKB];
 #pragma unroll
             for (int kb = 0; kb < PKB; ++kb)
-                if (kb < nb) v[kb] = __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(pa + (kp + kb) * 32));
+                if (kb < nb) v[kb] = *reinterpret_cast<const f16x8*>(pa + (kp + kb) * 32);
 #pragma unroll
             for (int kb = 0; kb < PKB; ++kb)
                 if (kb < nb) {
