@@ -2003,6 +2003,9 @@ struct radad_knn_s {
     float* cmu = nullptr;        // [dim] the common component, or nullptr: plane of the rows themselves
     float mu_norm = 0.f, mu_sq = 0.f;   // |mu| (rounded up: it enters error bounds) and |mu|^2 as summed on the device
     float* rbias = nullptr;      // [hi_cap] per-row bias of a centred plane: |y - mu|^2 (L2) or mu.y (IP / cosine)
+    float* kacc = nullptr;       // K-split tile scan (small stores of wide rows): partial accumulators of the two halves of a tile ...
+    int* kflag = nullptr;        // ... and the arrival counters (zero between launches)
+    int64_t kacc_tiles = 0;
     int uniform_e = HI_E_PER_ROW; // one power-of-two scale 2^e for every row of the plane (rows of one magnitude), or HI_E_PER_ROW
     // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
     // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
@@ -2322,6 +2325,8 @@ int radad_knn_destroy(radad_knn_t h) {
         if (h->cmu) (void)hipFree(h->cmu);
         if (h->rbias) (void)hipFree(h->rbias);
         if (h->stat) (void)hipFree(h->stat);
+        if (h->kacc) (void)hipFree(h->kacc);
+        if (h->kflag) (void)hipFree(h->kflag);
         if (h->host_count) (void)hipHostFree(h->host_count);
         for (int i = 0; i < 2; ++i) if (h->ev_count[i]) (void)hipEventDestroy(h->ev_count[i]);
         if (h->ev_done) (void)hipEventDestroy(h->ev_done);
@@ -2442,6 +2447,31 @@ __global__ __launch_bounds__(256) void k_bf16_to_f32(const unsigned short* __res
 }
 
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// K split of the tile scan over two workgroups per tile: when a launch has one tile per workgroup, at most 128 workgroups (half the
+// chip) and at least 16 K steps (dim >= 1024) -- the reference's own store, 25 423 x 5376: 100 tiles of 84 K steps.  Returns 1 or 2 and
+// makes sure the scratch exists (allocated once per handle; the counters start, and are left, at zero).
+static int knn_tile_ksplit(radad_knn_t h, int qtiles_grid, int n_splits, int64_t chunk_rows, int64_t rows, hipStream_t st) {
+    const int64_t tiles = ceil_div64(rows, KW_M);
+    if (chunk_rows != KW_M || (int64_t)qtiles_grid * n_splits > 128 || h->dim * 2 / 128 < 16) return 1;
+    const int64_t need = tiles * qtiles_grid;
+    if (need > h->kacc_tiles) {
+        (void)hipStreamSynchronize(st);
+        if (h->kacc) (void)hipFree(h->kacc);
+        if (h->kflag) (void)hipFree(h->kflag);
+        h->kacc = nullptr; h->kflag = nullptr; h->kacc_tiles = 0;
+        if (hipMalloc(&h->kacc, (size_t)need * 2 * 32 * KW_THREADS * sizeof(f32x4)) != hipSuccess ||
+            hipMalloc(&h->kflag, (size_t)need * sizeof(int)) != hipSuccess || hipMemset(h->kflag, 0, (size_t)need * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h->kacc) (void)hipFree(h->kacc);
+            if (h->kflag) (void)hipFree(h->kflag);
+            h->kacc = nullptr; h->kflag = nullptr;
+            return 1;                                   // no room: the un-split launch is always possible
+        }
+        h->kacc_tiles = need;
+    }
+    return 2;
+}
 
 // The search proper.  `margin` spare entries per (query, chunk) list on the fp32 tile kernels (KNN_MARGIN for user
 // searches; the IVF coarse quantiser asks for fewer so that nprobe = 32 still fits the 32-entry register lists).
@@ -2666,6 +2696,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         wp.n_qtiles = n_qtiles; wp.part_score = ps; wp.part_idx = pi;
         wp.cand_cap = emit_cap; wp.cand_cnt = cand_cnt;
         wp.thr_init = nullptr;
+        wp.ksplit = 1; wp.kacc = nullptr; wp.kflag = nullptr;
         wp.debug = 0; wp.stamps = nullptr;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (make exp); never in the shipped library
         { const char* dbg = getenv("RADAD_DEBUG_KNN"); wp.debug = dbg ? atoi(dbg) : 0; }
@@ -2692,7 +2723,10 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         {
             KnnHiParams sp = wp;
             sp.n = (int64_t)s_splits * KW_M; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
-            const dim3 sg((unsigned)((sp.n_qtiles <= 8 ? sp.n_qtiles : (sp.n_qtiles + 7) / 8 * 8) * sp.n_splits)), sb(KW_THREADS);
+            const int sq_grid = sp.n_qtiles <= 8 ? sp.n_qtiles : (sp.n_qtiles + 7) / 8 * 8;
+            sp.ksplit = knn_tile_ksplit(h, sq_grid, sp.n_splits, KW_M, sp.n, st);
+            sp.kacc = h->kacc; sp.kflag = h->kflag;
+            const dim3 sg((unsigned)(sq_grid * sp.n_splits * sp.ksplit)), sb(KW_THREADS);
             if (rsc == 0) hipLaunchKernelGGL(k_knn_hi_sample<0>, sg, sb, lds, st, sp);
             else if (rsc == 1) hipLaunchKernelGGL(k_knn_hi_sample<1>, sg, sb, lds, st, sp);
             else if (rsc == 2) hipLaunchKernelGGL(k_knn_hi_sample<2>, sg, sb, lds, st, sp);
@@ -2714,7 +2748,10 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             knn_geometry_wide(rp.n, nq, &gq, &gs, &gc);
             rp.n_splits = gs; rp.chunk_rows = gc;
             h->last_splits = gs;
-            const dim3 g2((unsigned)((gq <= 8 ? gq : (gq + 7) / 8 * 8) * gs));      // (more than 8 query tiles: whole groups of 8, see the kernel)
+            const int gq_grid = gq <= 8 ? gq : (gq + 7) / 8 * 8;                      // (more than 8 query tiles: whole groups of 8, see the kernel)
+            rp.ksplit = knn_tile_ksplit(h, gq_grid, gs, gc, rp.n, st);
+            rp.kacc = h->kacc; rp.kflag = h->kflag;
+            const dim3 g2((unsigned)(gq_grid * gs * rp.ksplit));
             h->prof.begin(st);      // the event pair brackets a scan launch only (the kernel the roofline is quoted on; the phases of one
                                     // search are two entries)
             if (rsc == 0) hipLaunchKernelGGL(k_knn_hi<0>, g2, b, lds, st, rp);
