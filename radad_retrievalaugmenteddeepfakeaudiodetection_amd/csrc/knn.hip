@@ -2696,7 +2696,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         wp.n_qtiles = n_qtiles; wp.part_score = ps; wp.part_idx = pi;
         wp.cand_cap = emit_cap; wp.cand_cnt = cand_cnt;
         wp.thr_init = nullptr;
-        wp.ksplit = 1; wp.kacc = nullptr; wp.kflag = nullptr;
+        wp.ksplit = 1; wp.kacc = nullptr; wp.kflag = nullptr; wp.loose_floor = 0;
         wp.debug = 0; wp.stamps = nullptr;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (make exp); never in the shipped library
         { const char* dbg = getenv("RADAD_DEBUG_KNN"); wp.debug = dbg ? atoi(dbg) : 0; }
@@ -2744,6 +2744,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             rp.rscale = wp.rscale ? wp.rscale + r0 : nullptr;
             rp.rbias = wp.rbias ? wp.rbias + r0 : nullptr;
             rp.n = r1 - r0; rp.id_off = r0;
+            rp.loose_floor = (r0 == 0 && r1 == h->ntotal && s_splits < KW_SAMPLE_SPLITS) ? 1 : 0;      // one launch behind a small sample
             int gq, gs; int64_t gc;
             knn_geometry_wide(rp.n, nq, &gq, &gs, &gc);
             rp.n_splits = gs; rp.chunk_rows = gc;
