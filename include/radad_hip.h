@@ -289,6 +289,11 @@ int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_
  * [0, n_samples_total]; bit 1 non-monotone offsets; bit 2 more segments than n_samples_total / hop + n_clips.  A non-zero
  * value means the embeddings of that batch are NOT those of the intended clips. */
 int radad_embed_plan_flags(radad_embed_t h, int* flags_out);
+/* Which log-mel kernel the most recent embedding call took: 0 = one transform per (segment, frame) (k_logmel_h, or k_logmel under
+ * RADAD_LOGMEL_F32); 1 = the frames overlapping segments share were transformed once per CLIP (k_logmel_h_clip: chosen by the
+ * configuration -- segment hop a multiple of 160 samples and smaller than the segment, Slaney filter bank -- for calls that hand over
+ * clips; RADAD_LOGMEL_SHARED=0 turns it off).  Both give feature_extraction_whisper.py:135-168 per zero-mean/unit-variance segment. */
+int radad_embed_last_logmel_kind(radad_embed_t h, int* kind_out);
 
 /* same HIP-event timing for the two embedding kernels (k_logmel, k_proj_pool) of radad_embed_forward */
 int radad_embed_profile(radad_embed_t h, int enable);

@@ -85,6 +85,16 @@ struct LogmelParams {
     int split_f0;                // k_logmel_h: frames of a segment's first workgroup (the second takes the rest; >= nf: one workgroup)
     int plane_halfs;             // k_logmel_h: halfs per LDS plane of a workgroup
     int n_seg;                   // k_logmel_h: segments of this launch (its grid is rounded up)
+    // k_logmel_h_clip (frames of overlapping segments transformed once: logmel_h.inc)
+    const float* seg_stats;      // [S][2] mean, 1 / sqrt(var + 1e-7) of every segment (k_seg_stats)
+    const int64_t* clip_seg;     // [clips + 1] first segment of every clip
+    const int* chunk_clip;       // [chunk_cap] clip of every interior chunk
+    const int64_t* clip_chunk;   // [clips + 1] first chunk of every clip
+    int seg_hop;                 // segment hop in samples, and ...
+    int seg_hop_frames;          // ... in frames (H)
+    int chunk_cap;               // workgroups [0, chunk_cap) are interior chunks (those past the true count leave), the rest edge frames
+    int n_chunks;                // true count when the plan was sized on the host (else n_seg_dev[2])
+    float fb1[2];                // filter-bank weights of bin 1 in mel bands 0 and 1
     int debug;                   // timing experiments only (RADAD_DEBUG_LOGMEL): 1 = skip the MFMA loop, 2 = skip the prologue
 };
 
@@ -541,13 +551,17 @@ __global__ __launch_bounds__(256) void k_group_mean(const float* __restrict__ in
 // -1: unknown, only negative lengths are repaired) and the segment count to seg_cap, so that whatever the tensor holds the kernels
 // behind this one read inside the wave buffer and inside their own scratch.  n_seg_out[1] reports what had to be repaired:
 // bit 0 an offset outside [0, total], bit 1 a clip ending before it starts, bit 2 more segments than seg_cap.
+// Chunk plan of k_logmel_h_clip (share_T > 0): a clip of S segments has (S - 1) H + T - 3 interior frames, cut into
+// ceil(. / chunk_frames) chunks; clip_chunk[] is their exclusive prefix, chunk_clip[] maps a chunk back to its clip, n_seg_out[2] counts them.
 __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__ off, int64_t n_clips, int L, int hop,
                                                      int64_t seg_cap, int64_t total, int64_t* __restrict__ clip_seg,
-                                                     int64_t* __restrict__ seg_start, int* __restrict__ seg_valid, int* __restrict__ n_seg_out) {
+                                                     int64_t* __restrict__ seg_start, int* __restrict__ seg_valid, int* __restrict__ n_seg_out,
+                                                     int share_T, int share_H, int chunk_frames, int64_t chunk_cap,
+                                                     int64_t* __restrict__ clip_chunk, int* __restrict__ chunk_clip) {
     __shared__ long long s_wave[16];
-    __shared__ long long s_carry;
+    __shared__ long long s_carry, s_carry_c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_carry = 0;
+    if (tid == 0) { s_carry = 0; s_carry_c = 0; }
     __syncthreads();
     int bad = 0;
     for (int64_t b0 = 0; b0 < n_clips; b0 += 1024) {
@@ -592,12 +606,41 @@ __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__
         __syncthreads();
         if (tid == 1023) s_carry = base + inc;
         __syncthreads();
+        if (share_T > 0) {                               // the same scan over the clips' chunk counts
+            const long long first_seg = first < seg_cap ? first : seg_cap;
+            const long long S = (b < n_clips) ? ((first + ns < seg_cap ? first + ns : seg_cap) - first_seg) : 0;     // segments that made it into the plan
+            const long long ni = S > 0 ? (S - 1) * share_H + share_T - 3 : 0;
+            const long long nc = (ni + chunk_frames - 1) / chunk_frames;
+            long long incc = nc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const long long t = __shfl_up(incc, o, 64);
+                if (lane >= o) incc += t;
+            }
+            if (lane == 63) s_wave[wave] = incc;
+            __syncthreads();
+            long long basec = s_carry_c;
+            for (int w = 0; w < wave; ++w) basec += s_wave[w];
+            const long long firstc = basec + incc - nc;
+            if (b < n_clips) {
+                clip_chunk[b] = firstc;
+                for (long long i = 0; i < nc; ++i)
+                    if (firstc + i < chunk_cap) chunk_clip[firstc + i] = (int)b;
+            }
+            __syncthreads();
+            if (tid == 1023) s_carry_c = basec + incc;
+            __syncthreads();
+        }
     }
     bad = (__syncthreads_or(bad & 1) ? 1 : 0) | (__syncthreads_or(bad & 2) ? 2 : 0);      // (a predicate per flag: the builtin ORs truth values)
     if (tid == 0) {
         clip_seg[n_clips] = s_carry < seg_cap ? s_carry : seg_cap;
         n_seg_out[0] = (int)(s_carry < seg_cap ? s_carry : seg_cap);
         n_seg_out[1] = bad | (s_carry > seg_cap ? 4 : 0);
+        if (share_T > 0) {
+            clip_chunk[n_clips] = s_carry_c;
+            n_seg_out[2] = (int)(s_carry_c < chunk_cap ? s_carry_c : chunk_cap);
+        }
     }
 }
 
@@ -634,6 +677,16 @@ struct radad_embed_s {
     _Float16* wfrag_h = nullptr;
     _Float16* basis_h = nullptr;
     int logmel_f32 = 0;                  // RADAD_LOGMEL_F32=1: the fp32-MFMA kernel (k_logmel) instead of k_logmel_h
+    // k_logmel_h_clip: frames shared by overlapping segments are transformed once (logmel_h.inc).  Possible when the segment hop is a
+    // multiple of the frame hop and smaller than the segment, at most LH_MAX_OWNERS segments share a frame, and the filter bank
+    // has the Slaney shape the mean correction relies on (bin 0 without weight, bin 1 only in bands 0 and 1)
+    int share_frames = 0;                // 1: batches given as clips take k_logmel_h_clip (RADAD_LOGMEL_SHARED=0 turns it off)
+    int share_H = 0;                     // segment hop in frames
+    float fb1[2] = {0.f, 0.f};
+    int64_t plan_nchunks = 0;            // interior chunks of the cached plan (host-sized plans), or their upper bound (device-sized)
+    bool plan_has_chunks = false;        // the cached plan carries the chunk arrays
+    DevBuf seg_stats, chunk_clip, clip_chunk;
+    int last_logmel_kind = 0;            // 0 per segment, 1 shared clip frames (radad_embed_last_logmel_kind)
     int* levels_dev = nullptr;
     // plan cache + scratch
     std::vector<int64_t> plan_key;       // the clip_offsets the cached plan was built from
@@ -670,16 +723,29 @@ static int upload(DevBuf& b, const void* host, size_t bytes, hipStream_t st) {
 }
 
 // Launch k_build_plan over device-resident offsets.  seg_cap bounds the number of segments (buffers and grids).
-static int plan_on_device(radad_embed_t h, const int64_t* clip_off_dev, int64_t n_clips, int64_t seg_cap, int64_t total, hipStream_t st) {
+// chunk_cap: interior chunks of k_logmel_h_clip to plan for (0: no chunk plan).
+static int plan_on_device(radad_embed_t h, const int64_t* clip_off_dev, int64_t n_clips, int64_t seg_cap, int64_t total, hipStream_t st,
+                          int64_t chunk_cap = 0) {
     int rc;
     if ((rc = h->seg_start.ensure((size_t)seg_cap * sizeof(int64_t)))) return rc;
     if ((rc = h->seg_valid.ensure((size_t)seg_cap * sizeof(int32_t)))) return rc;
     if ((rc = h->clip_seg.ensure((size_t)(n_clips + 1) * sizeof(int64_t)))) return rc;
-    if ((rc = h->n_seg_dev.ensure(2 * sizeof(int)))) return rc;
+    if ((rc = h->n_seg_dev.ensure(4 * sizeof(int)))) return rc;
+    if (chunk_cap > 0) {
+        if ((rc = h->chunk_clip.ensure((size_t)chunk_cap * sizeof(int)))) return rc;
+        if ((rc = h->clip_chunk.ensure((size_t)(n_clips + 1) * sizeof(int64_t)))) return rc;
+    }
     hipLaunchKernelGGL(k_build_plan, dim3(1), dim3(1024), 0, st, clip_off_dev, n_clips, h->cfg.segment_length, h->cfg.hop_length,
-                       seg_cap, total, (int64_t*)h->clip_seg.p, (int64_t*)h->seg_start.p, (int*)h->seg_valid.p, (int*)h->n_seg_dev.p);
+                       seg_cap, total, (int64_t*)h->clip_seg.p, (int64_t*)h->seg_start.p, (int*)h->seg_valid.p, (int*)h->n_seg_dev.p,
+                       chunk_cap > 0 ? h->nf : 0, h->share_H, LH_CLIP_FRAMES, chunk_cap, (int64_t*)h->clip_chunk.p, (int*)h->chunk_clip.p);
     RADAD_HIP_CHECK(hipGetLastError());
+    h->plan_has_chunks = chunk_cap > 0;
+    h->plan_nchunks = chunk_cap;
     return RADAD_OK;
+}
+static int64_t clip_chunks(const radad_embed_s* h, int64_t n_segments_of_clip) {       // interior chunks of one clip
+    const int64_t ni = n_segments_of_clip > 0 ? (n_segments_of_clip - 1) * h->share_H + h->nf - 3 : 0;
+    return (ni + LH_CLIP_FRAMES - 1) / LH_CLIP_FRAMES;
 }
 
 // Plan for clip offsets in HOST memory (segmenter.py:25-39): the host only counts the segments (it needs the grid size);
@@ -690,7 +756,7 @@ static int build_plan(radad_embed_t h, const int64_t* clip_offsets, int64_t n_cl
         memcmp(h->plan_key.data(), clip_offsets, sizeof(int64_t) * (n_clips + 1)) == 0)
         return RADAD_OK;
     const int L = h->cfg.segment_length, hop = h->cfg.hop_length;
-    int64_t n_seg = 0, first = -1;
+    int64_t n_seg = 0, first = -1, n_chunks = 0;
     bool uniform = true;
     for (int64_t b = 0; b < n_clips; ++b) {
         const int64_t n = clip_offsets[b + 1] - clip_offsets[b];
@@ -699,6 +765,7 @@ static int build_plan(radad_embed_t h, const int64_t* clip_offsets, int64_t n_cl
         if (first < 0) first = ns;
         uniform = uniform && ns == first;
         n_seg += ns;
+        if (h->share_frames) n_chunks += clip_chunks(h, ns);
     }
     RADAD_REQUIRE(n_seg < (1ll << 31), "radad_embed_forward: too many segments in one batch");
     const int slot = h->pin_next;
@@ -717,7 +784,7 @@ static int build_plan(radad_embed_t h, const int64_t* clip_offsets, int64_t n_cl
     RADAD_HIP_CHECK(hipMemcpyAsync(h->clip_off.p, h->pin[slot], need, hipMemcpyHostToDevice, st));
     RADAD_HIP_CHECK(hipEventRecord(h->pin_ev[slot], st));
     h->pin_next ^= 1;
-    if ((rc = plan_on_device(h, (const int64_t*)h->clip_off.p, n_clips, std::max<int64_t>(n_seg, 1), -1, st))) return rc;
+    if ((rc = plan_on_device(h, (const int64_t*)h->clip_off.p, n_clips, std::max<int64_t>(n_seg, 1), -1, st, n_chunks))) return rc;
     h->plan_uniform = uniform;
     h->plan_on_device = false;
     h->plan_key.assign(clip_offsets, clip_offsets + n_clips + 1);
@@ -731,6 +798,7 @@ static int upload_plan_explicit(radad_embed_t h, const int64_t* seg_start, const
                       "segment %lld: bad start/valid", (long long)i);
     h->plan_key.clear();
     h->plan_on_device = false;
+    h->plan_has_chunks = false;
     RADAD_HIP_CHECK(hipStreamSynchronize(st));
     int rc;
     if ((rc = upload(h->seg_start, seg_start, n_seg * sizeof(int64_t), st))) return rc;
@@ -756,6 +824,8 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.seg_len = h->cfg.segment_length; p.normalize = h->cfg.normalize; p.padded = h->padded; p.nf = h->nf;
     p.basis = h->basis; p.basis_h = h->basis_h; p.fbfrag = h->fbfrag; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
     p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out; p.n_seg_dev = n_seg_dev;
+    p.seg_stats = nullptr; p.clip_seg = nullptr; p.chunk_clip = nullptr; p.clip_chunk = nullptr;
+    p.seg_hop = 0; p.seg_hop_frames = 0; p.chunk_cap = 0; p.n_chunks = 0; p.fb1[0] = p.fb1[1] = 0.f;
     p.debug = 0;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (tools/exp_logmel.sh builds with -DRADAD_DEBUG_HOOKS); never in the shipped library
     { const char* dbg = getenv("RADAD_DEBUG_LOGMEL"); p.debug = dbg ? atoi(dbg) : 0; }
@@ -765,7 +835,27 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.n_seg = (int)n_seg;
     const int wg_frames = std::max(p.split_f0, h->nf - p.split_f0);
     p.plane_halfs = lh_plane_halfs(wg_frames);
-    if (h->logmel_f32) hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
+    const bool clip_frames = h->share_frames && h->plan_has_chunks && !h->logmel_f32 && !norm_out;
+    h->last_logmel_kind = clip_frames ? 1 : 0;
+    if (clip_frames) {
+        // the segments' statistics first (the transform is shared, the normalisation is not), then chunks and edge frames in one grid
+        if ((rc = h->seg_stats.ensure((size_t)n_seg * 2 * sizeof(float)))) return rc;
+        if (h->cfg.normalize)
+            hipLaunchKernelGGL(k_seg_stats, dim3((unsigned)n_seg), dim3(LH_THREADS), 0, st, wave_dev, p.seg_start, p.seg_valid, p.seg_len,
+                               (int)n_seg, n_seg_dev, (float*)h->seg_stats.p);
+        p.seg_stats = (const float*)h->seg_stats.p;
+        p.clip_seg = (const int64_t*)h->clip_seg.p;
+        p.chunk_clip = (const int*)h->chunk_clip.p;
+        p.clip_chunk = (const int64_t*)h->clip_chunk.p;
+        p.seg_hop = h->cfg.hop_length;
+        p.seg_hop_frames = h->share_H;
+        p.chunk_cap = (int)h->plan_nchunks;
+        p.n_chunks = (int)h->plan_nchunks;
+        p.fb1[0] = h->fb1[0]; p.fb1[1] = h->fb1[1];
+        p.plane_halfs = lh_plane_halfs(LH_CLIP_FRAMES);
+        const int64_t edge_wgs = (3 * n_seg + LH_EDGE_FRAMES - 1) / LH_EDGE_FRAMES;
+        hipLaunchKernelGGL(k_logmel_h_clip, dim3((unsigned)(h->plan_nchunks + edge_wgs)), dim3(LH_THREADS), logmel_h_lds_bytes(LH_CLIP_FRAMES), st, p);
+    } else if (h->logmel_f32) hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
     else hipLaunchKernelGGL(k_logmel_h, dim3((unsigned)(16 * ((n_seg + 7) / 8))), dim3(LH_THREADS), logmel_h_lds_bytes(wg_frames), st, p);
     h->prof_logmel.end(st);
     RADAD_HIP_CHECK(hipGetLastError());
@@ -929,6 +1019,22 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
         if (hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { radad_set_error("H2D copy failed"); return RADAD_EHIP; }
         return RADAD_OK;
     };
+    {
+        // shared clip frames: the configuration decides (the data never does: padded and ragged clips are handled inside the kernel)
+        const int hopf = cfg->hop_length / FFT_HOP;
+        bool ok = padded == L && cfg->hop_length % FFT_HOP == 0 && cfg->hop_length < L && nf == T && T >= 8 && hopf >= 1 &&
+                  (T - 4) / hopf + 1 <= LH_MAX_OWNERS;
+        for (int mel = 0; mel < N_MELS && ok; ++mel) {
+            if (mel_filters_host[0 * N_MELS + mel] != 0.f) ok = false;               // bin 0 must carry no weight
+            if (mel >= 2 && mel_filters_host[1 * N_MELS + mel] != 0.f) ok = false;    // bin 1 only in bands 0 and 1
+        }
+        const char* e = radad_env_override("RADAD_LOGMEL_SHARED", "0 keeps one log-mel transform per (segment, frame) even where overlapping segments share frames (k_logmel_h instead of k_logmel_h_clip), for extractors created from now on");
+        if (e && atoi(e) == 0) ok = false;
+        h->share_frames = ok ? 1 : 0;
+        h->share_H = ok ? hopf : 0;
+        h->fb1[0] = mel_filters_host[1 * N_MELS + 0];
+        h->fb1[1] = mel_filters_host[1 * N_MELS + 1];
+    }
     { const char* e = radad_env_override("RADAD_LOGMEL_F32", "non-zero selects the fp32-MFMA log-mel kernel (k_logmel, ~2x slower) for extractors created from now on"); h->logmel_f32 = (e && atoi(e) != 0) ? 1 : 0; }
     int rc = put(&h->basis, basis.data(), basis.size() * sizeof(float));
     if (!rc) rc = put((float**)&h->basis_h, basis_h.data(), basis_h.size() * sizeof(_Float16));
@@ -941,6 +1047,8 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)logmel_lds_bytes()) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel_h), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)logmel_h_lds_bytes(LH_WG_FRAMES)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel_h_clip), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)logmel_h_lds_bytes(LH_WG_FRAMES)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)projpool_lds_bytes(8)) != hipSuccess ||
@@ -970,6 +1078,7 @@ int radad_embed_destroy(radad_embed_t h) {
         if (h->levels_dev) (void)hipFree(h->levels_dev);
         h->seg_start.release(); h->seg_valid.release(); h->clip_seg.release(); h->logmel.release(); h->seg_max.release();
         h->seg_pool.release(); h->clip_off.release(); h->n_seg_dev.release();
+        h->seg_stats.release(); h->chunk_clip.release(); h->clip_chunk.release();
         for (int i = 0; i < 2; ++i) {
             if (h->pin[i]) (void)hipHostFree(h->pin[i]);
             if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
@@ -1056,7 +1165,10 @@ int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_
     // bound, the kernels read the true count from the device
     const int64_t seg_cap = n_samples_total / h->cfg.hop_length + n_clips;
     RADAD_REQUIRE(seg_cap < (1ll << 31), "radad_embed_forward_dev: too many segments in one batch");
-    int rc = plan_on_device(h, clip_offsets_dev, n_clips, seg_cap, n_samples_total, st);
+    // interior chunks: a clip of S segments has ceil(((S - 1) H + T - 3) / 104) <= (S H + T) / 104 + 1 of them
+    const int64_t chunk_cap = h->share_frames ? (seg_cap * h->share_H + n_clips * h->nf) / LH_CLIP_FRAMES + n_clips + 1 : 0;
+    RADAD_REQUIRE(chunk_cap < (1ll << 30), "radad_embed_forward_dev: too many frames in one batch");
+    int rc = plan_on_device(h, clip_offsets_dev, n_clips, seg_cap, n_samples_total, st, chunk_cap);
     if (rc) return rc;
     h->plan_key.clear();
     h->plan_on_device = true;
@@ -1082,6 +1194,13 @@ int radad_embed_plan_flags(radad_embed_t h, int* flags_out) {
     RADAD_HIP_CHECK(hipEventSynchronize(h->plan_flags_ev));
     *flags_out = *h->plan_flags_host;
     h->plan_flags_pending = false;           // reported once
+    return RADAD_OK;
+}
+
+int radad_embed_last_logmel_kind(radad_embed_t h, int* kind_out) {
+    RADAD_REQUIRE(h && kind_out, "radad_embed_last_logmel_kind: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    *kind_out = h->last_logmel_kind;
     return RADAD_OK;
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Lint for k_logmel_h's hand-counted load queue (csrc/logmel_h.inc): compiles csrc/embed.hip to gfx950 assembly and checks
+"""Lint for the hand-counted load queue of k_logmel_h / k_logmel_h_clip (csrc/logmel_h.inc): compiles csrc/embed.hip to gfx950 assembly and checks
 
   1. that from the first queue load on NO compiler-generated instruction of the kernel names a register in v176..v255 -- those
      belong to the queue's inline asm (the kernel is compiled with amdgpu_num_vgpr(176) and every asm block clobbers them all);
@@ -24,7 +24,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "radad_retrievalaugmenteddeepfakeaudiodetection_amd", "csrc")
-KERNEL = "k_logmel_h"
+KERNELS = ("k_logmel_h", "k_logmel_h_clip")
 QUEUE_REGS = set(range(176, 256))
 REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
 
@@ -42,7 +42,7 @@ def regs_of(text):
 def kernel_text(asm, name):
     """[(instruction text without comment, inside an inline-asm block?)] of the kernel"""
     lines = asm.splitlines()
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*%s\w*:" % name, l))
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*?%d%sE\w*:" % (len(name), name), l))     # (mangled: <length><name>E)
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     out, in_asm = [], False
     for l in lines[start + 1:end + 1]:
@@ -130,20 +130,22 @@ def main():
             cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"),
                    "--cuda-device-only", "-S", os.path.join(CSRC, "embed.hip"), "-o", out] + flags
             subprocess.run(cmd, check=True, cwd=tmp, stderr=subprocess.DEVNULL)
-            lines = kernel_text(open(out).read(), KERNEL)
-        reserved = check_reserved(lines)
-        msgs, order = check_blocks(lines)
-        if flags:            # basic-block layout of the tools-only variant differs (its loops can be skipped): text order says nothing there
-            msgs = [m for m in msgs if "not cyclic" not in m]
-        tag = " ".join(flags) or "shipped flags"
-        print(f"{KERNEL} [{tag}]: {len(lines)} lines, {len(asm_blocks(lines))} asm blocks, slot order {''.join(map(str, order))}")
-        print(f"  {len(reserved)} compiler-generated instruction(s) naming v176..v255 after the first queue load")
-        for n, ins in reserved[:20]:
-            print(f"    line {n}: {ins}")
-        print(f"  {len(msgs)} structural problem(s)")
-        for m in msgs[:20]:
-            print(f"    {m}")
-        rc |= 1 if (reserved or msgs) else 0
+            asm = open(out).read()
+        for kernel in KERNELS:
+            lines = kernel_text(asm, kernel)
+            reserved = check_reserved(lines)
+            msgs, order = check_blocks(lines)
+            if flags:        # basic-block layout of the tools-only variant differs (its loops can be skipped): text order says nothing there
+                msgs = [m for m in msgs if "not cyclic" not in m]
+            tag = " ".join(flags) or "shipped flags"
+            print(f"{kernel} [{tag}]: {len(lines)} lines, {len(asm_blocks(lines))} asm blocks, slot order {''.join(map(str, order))}")
+            print(f"  {len(reserved)} compiler-generated instruction(s) naming v176..v255 after the first queue load")
+            for n, ins in reserved[:20]:
+                print(f"    line {n}: {ins}")
+            print(f"  {len(msgs)} structural problem(s)")
+            for m in msgs[:20]:
+                print(f"    {m}")
+            rc |= 1 if (reserved or msgs) else 0
     return rc
 
 
