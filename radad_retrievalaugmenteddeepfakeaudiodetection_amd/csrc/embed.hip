@@ -93,8 +93,6 @@ struct LogmelParams {
     int seg_hop;                 // segment hop in samples, and ...
     int seg_hop_frames;          // ... in frames (H)
     int chunk_cap;               // grid size: chunks (workgroups past the true count leave)
-    int chunk_frames;            // interior frames per chunk at most (<= 104, <= 2 H - 6)
-    int edge_base;               // halfs: where the edge windows start in each LDS plane
     int n_chunks;                // true count when the plan was sized on the host (else n_seg_dev[2])
     float fb1[2];                // filter-bank weights of bin 1 in mel bands 0 and 1
     int debug;                   // timing experiments only (RADAD_DEBUG_LOGMEL): 1 = skip the MFMA loop, 2 = skip the prologue
@@ -553,12 +551,12 @@ __global__ __launch_bounds__(256) void k_group_mean(const float* __restrict__ in
 // -1: unknown, only negative lengths are repaired) and the segment count to seg_cap, so that whatever the tensor holds the kernels
 // behind this one read inside the wave buffer and inside their own scratch.  n_seg_out[1] reports what had to be repaired:
 // bit 0 an offset outside [0, total], bit 1 a clip ending before it starts, bit 2 more segments than seg_cap.
-// Chunk plan of k_logmel_h_clip (share_T > 0): a clip of S segments has (S - 1) H + T - 3 interior frames, cut into
-// ceil(. / chunk_frames) chunks; clip_chunk[] is their exclusive prefix, chunk_clip[] maps a chunk back to its clip, n_seg_out[2] counts them.
+// Chunk plan of k_logmel_h_clip (share_T > 0): a clip of S segments is cut into clip_chunk_count(S, T, H) chunks (logmel_h.inc);
+// clip_chunk[] is their exclusive prefix, chunk_clip[] maps a chunk back to its clip, n_seg_out[2] counts them.
 __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__ off, int64_t n_clips, int L, int hop,
                                                      int64_t seg_cap, int64_t total, int64_t* __restrict__ clip_seg,
                                                      int64_t* __restrict__ seg_start, int* __restrict__ seg_valid, int* __restrict__ n_seg_out,
-                                                     int share_T, int share_H, int chunk_frames, int64_t chunk_cap,
+                                                     int share_T, int share_H, int64_t chunk_cap,
                                                      int64_t* __restrict__ clip_chunk, int* __restrict__ chunk_clip) {
     __shared__ long long s_wave[16];
     __shared__ long long s_carry, s_carry_c;
@@ -611,8 +609,7 @@ __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__
         if (share_T > 0) {                               // the same scan over the clips' chunk counts
             const long long first_seg = first < seg_cap ? first : seg_cap;
             const long long S = (b < n_clips) ? ((first + ns < seg_cap ? first + ns : seg_cap) - first_seg) : 0;     // segments that made it into the plan
-            const long long ni = S > 0 ? (S - 1) * share_H + share_T - 3 : 0;
-            const long long nc = (ni + chunk_frames - 1) / chunk_frames;
+            const long long nc = clip_chunk_count((int)S, share_T, share_H);
             long long incc = nc;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -684,7 +681,6 @@ struct radad_embed_s {
     // has the Slaney shape the mean correction relies on (bin 0 without weight, bin 1 only in bands 0 and 1)
     int share_frames = 0;                // 1: batches given as clips take k_logmel_h_clip (RADAD_LOGMEL_SHARED=0 turns it off)
     int share_H = 0;                     // segment hop in frames
-    int chunk_frames = 0;                // interior frames per chunk workgroup
     float fb1[2] = {0.f, 0.f};
     int64_t plan_nchunks = 0;            // interior chunks of the cached plan (host-sized plans), or their upper bound (device-sized)
     bool plan_has_chunks = false;        // the cached plan carries the chunk arrays
@@ -740,15 +736,14 @@ static int plan_on_device(radad_embed_t h, const int64_t* clip_off_dev, int64_t 
     }
     hipLaunchKernelGGL(k_build_plan, dim3(1), dim3(1024), 0, st, clip_off_dev, n_clips, h->cfg.segment_length, h->cfg.hop_length,
                        seg_cap, total, (int64_t*)h->clip_seg.p, (int64_t*)h->seg_start.p, (int*)h->seg_valid.p, (int*)h->n_seg_dev.p,
-                       chunk_cap > 0 ? h->nf : 0, h->share_H, h->chunk_frames, chunk_cap, (int64_t*)h->clip_chunk.p, (int*)h->chunk_clip.p);
+                       chunk_cap > 0 ? h->nf : 0, h->share_H, chunk_cap, (int64_t*)h->clip_chunk.p, (int*)h->chunk_clip.p);
     RADAD_HIP_CHECK(hipGetLastError());
     h->plan_has_chunks = chunk_cap > 0;
     h->plan_nchunks = chunk_cap;
     return RADAD_OK;
 }
-static int64_t clip_chunks(const radad_embed_s* h, int64_t n_segments_of_clip) {       // interior chunks of one clip
-    const int64_t ni = n_segments_of_clip > 0 ? (n_segments_of_clip - 1) * h->share_H + h->nf - 3 : 0;
-    return (ni + h->chunk_frames - 1) / h->chunk_frames;
+static int64_t clip_chunks(const radad_embed_s* h, int64_t n_segments_of_clip) {       // chunks of one clip
+    return clip_chunk_count((int)n_segments_of_clip, h->nf, h->share_H);
 }
 
 // Plan for clip offsets in HOST memory (segmenter.py:25-39): the host only counts the segments (it needs the grid size);
@@ -828,7 +823,7 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.basis = h->basis; p.basis_h = h->basis_h; p.fbfrag = h->fbfrag; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
     p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out; p.n_seg_dev = n_seg_dev;
     p.seg_stats = nullptr; p.clip_seg = nullptr; p.chunk_clip = nullptr; p.clip_chunk = nullptr;
-    p.seg_hop = 0; p.seg_hop_frames = 0; p.chunk_cap = 0; p.n_chunks = 0; p.fb1[0] = p.fb1[1] = 0.f; p.chunk_frames = 0; p.edge_base = 0;
+    p.seg_hop = 0; p.seg_hop_frames = 0; p.chunk_cap = 0; p.n_chunks = 0; p.fb1[0] = p.fb1[1] = 0.f;
     p.debug = 0;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (tools/exp_logmel.sh builds with -DRADAD_DEBUG_HOOKS); never in the shipped library
     { const char* dbg = getenv("RADAD_DEBUG_LOGMEL"); p.debug = dbg ? atoi(dbg) : 0; }
@@ -855,9 +850,7 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
         p.chunk_cap = (int)h->plan_nchunks;
         p.n_chunks = (int)h->plan_nchunks;
         p.fb1[0] = h->fb1[0]; p.fb1[1] = h->fb1[1];
-        p.chunk_frames = h->chunk_frames;
-        p.edge_base = lh_plane_halfs(LH_CLIP_FRAMES);
-        p.plane_halfs = lh_clip_plane_halfs();
+        p.plane_halfs = LH_CLIP_PLANE_HALFS;
         hipLaunchKernelGGL(k_logmel_h_clip, dim3((unsigned)h->plan_nchunks), dim3(LH_THREADS), logmel_h_clip_lds_bytes(), st, p);
     } else if (h->logmel_f32) hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
     else hipLaunchKernelGGL(k_logmel_h, dim3((unsigned)(16 * ((n_seg + 7) / 8))), dim3(LH_THREADS), logmel_h_lds_bytes(wg_frames), st, p);
@@ -1026,8 +1019,7 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
     {
         // shared clip frames: the configuration decides (the data never does: padded and ragged clips are handled inside the kernel)
         const int hopf = cfg->hop_length / FFT_HOP;
-        // (chunks of <= 2 H - 6 interior frames: a clip of S segments then has >= S / 2 chunks for its 3 S edge frames, <= LH_EDGE_MAX each)
-        bool ok = padded == L && cfg->hop_length % FFT_HOP == 0 && cfg->hop_length < L && nf == T && T >= 8 && hopf >= 16 &&
+        bool ok = padded == L && cfg->hop_length % FFT_HOP == 0 && cfg->hop_length < L && nf == T && T >= 8 && hopf >= 1 &&
                   (T - 4) / hopf + 1 <= LH_MAX_OWNERS;
         for (int mel = 0; mel < N_MELS && ok; ++mel) {
             if (mel_filters_host[0 * N_MELS + mel] != 0.f) ok = false;               // bin 0 must carry no weight
@@ -1037,7 +1029,6 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
         if (e && atoi(e) == 0) ok = false;
         h->share_frames = ok ? 1 : 0;
         h->share_H = ok ? hopf : 0;
-        h->chunk_frames = ok ? std::min(LH_CLIP_FRAMES, 2 * hopf - 6) : 0;
         h->fb1[0] = mel_filters_host[1 * N_MELS + 0];
         h->fb1[1] = mel_filters_host[1 * N_MELS + 1];
     }
@@ -1171,8 +1162,9 @@ int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_
     // bound, the kernels read the true count from the device
     const int64_t seg_cap = n_samples_total / h->cfg.hop_length + n_clips;
     RADAD_REQUIRE(seg_cap < (1ll << 31), "radad_embed_forward_dev: too many segments in one batch");
-    // interior chunks: a clip of S segments has ceil(((S - 1) H + T - 3) / chunk_frames) <= (S H + T) / chunk_frames + 1 of them
-    const int64_t chunk_cap = h->share_frames ? (seg_cap * h->share_H + n_clips * h->nf) / h->chunk_frames + n_clips + 1 : 0;
+    // chunks: a clip of S segments has <= ((S - 1) H + T) / 96 + 1 + 3 S / 32 + 1 of them
+    const int64_t chunk_cap = h->share_frames ? (seg_cap * h->share_H + n_clips * h->nf) / LH_CLIP_FRAMES + (3 * seg_cap) / LH_EDGE_CHUNK +
+                                                    2 * n_clips + 1 : 0;
     RADAD_REQUIRE(chunk_cap < (1ll << 30), "radad_embed_forward_dev: too many frames in one batch");
     int rc = plan_on_device(h, clip_offsets_dev, n_clips, seg_cap, n_samples_total, st, chunk_cap);
     if (rc) return rc;
