@@ -86,7 +86,7 @@ struct LogmelParams {
     int plane_halfs;             // k_logmel_h: halfs per LDS plane of a workgroup
     int n_seg;                   // k_logmel_h: segments of this launch (its grid is rounded up)
     // k_logmel_h_clip (frames of overlapping segments transformed once: logmel_h.inc)
-    const float* seg_stats;      // [S][2] mean, 1 / sqrt(var + 1e-7) of every segment (k_seg_stats)
+    const float* seg_stats;      // [S][4] mean, inv = 1 / sqrt(var + 1e-7), inv^2, 2 log10(inv) of every segment (k_seg_stats)
     const int64_t* clip_seg;     // [clips + 1] first segment of every clip
     const int* chunk_clip;       // [chunk_cap] clip of every interior chunk
     const int64_t* clip_chunk;   // [clips + 1] first chunk of every clip
@@ -837,7 +837,7 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     h->last_logmel_kind = clip_frames ? 1 : 0;
     if (clip_frames) {
         // the segments' statistics first (the transform is shared, the normalisation is not), then chunks and edge frames in one grid
-        if ((rc = h->seg_stats.ensure((size_t)n_seg * 2 * sizeof(float)))) return rc;
+        if ((rc = h->seg_stats.ensure((size_t)n_seg * 4 * sizeof(float)))) return rc;
         if (h->cfg.normalize)
             hipLaunchKernelGGL(k_seg_stats, dim3((unsigned)n_seg), dim3(LH_THREADS), 0, st, wave_dev, p.seg_start, p.seg_valid, p.seg_len,
                                (int)n_seg, n_seg_dev, (float*)h->seg_stats.p);
