@@ -1,4 +1,4 @@
-"""CPU: the generated gfx950 code of k_logmel_h keeps to the rules its hand-counted load queue depends on (tools/check_asm_queue.py:
+"""CPU: the generated gfx950 code of k_logmel_h and k_logmel_h_clip (one body, two instantiations) keeps to the rules its hand-counted load queue depends on (tools/check_asm_queue.py:
 no compiler-generated instruction touches the queue's fixed registers once the queue runs; every asm block waits before it reads
 a slot and refills it afterwards; slots in cyclic order).  Compiles csrc/embed.hip to assembly (hipcc cross-compiles without a GPU)."""
 import importlib.util
@@ -23,4 +23,4 @@ def test_logmel_queue_registers_are_left_alone(capsys):
         sys.argv = argv
     out = capsys.readouterr().out
     assert rc == 0, out
-    assert "slot order 012340123401234" in out, out
+    assert out.count("slot order 012340123401234") == 2, out          # both kernels
