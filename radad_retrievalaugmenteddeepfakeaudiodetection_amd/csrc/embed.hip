@@ -66,6 +66,14 @@ __device__ __forceinline__ float block_sum(float v, float* scratch, int nwaves) 
     return t;
 }
 
+// one chunk of k_logmel_h_clip's work list (logmel_h.inc): clip, position in the clip
+struct ChunkRec {
+    int64_t beg;                 // absolute sample offset of the clip
+    int seg0, n_seg;             // the clip's first segment in the launch's segment list, its segments
+    int cidx;                    // index of the chunk inside the clip
+    int avail;                   // samples of the clip its segments cover (the rest reads as zero)
+};
+
 struct LogmelParams {
     const float* wave;           // all clips, back to back
     const int64_t* seg_start;    // [S] absolute sample offset of each segment
@@ -88,8 +96,8 @@ struct LogmelParams {
     // k_logmel_h_clip (frames of overlapping segments transformed once: logmel_h.inc)
     const float* seg_stats;      // [S][4] mean, inv = 1 / sqrt(var + 1e-7), inv^2, 2 log10(inv) of every segment (k_seg_stats)
     const int64_t* clip_seg;     // [clips + 1] first segment of every clip
-    const int* chunk_clip;       // [chunk_cap] clip of every interior chunk
-    const int64_t* clip_chunk;   // [clips + 1] first chunk of every clip
+    const ChunkRec* chunk_rec;   // [chunk_cap] what a chunk workgroup needs to know, in one record (k_build_plan)
+    int prefetch_dist;           // a chunk workgroup touches the samples of chunk (own index + this) while its matrix phase runs
     int seg_hop;                 // segment hop in samples, and ...
     int seg_hop_frames;          // ... in frames (H)
     int chunk_cap;               // grid size: chunks (workgroups past the true count leave)
@@ -552,12 +560,12 @@ __global__ __launch_bounds__(256) void k_group_mean(const float* __restrict__ in
 // behind this one read inside the wave buffer and inside their own scratch.  n_seg_out[1] reports what had to be repaired:
 // bit 0 an offset outside [0, total], bit 1 a clip ending before it starts, bit 2 more segments than seg_cap.
 // Chunk plan of k_logmel_h_clip (share_T > 0): a clip of S segments is cut into clip_chunk_count(S, T, H) chunks (logmel_h.inc);
-// clip_chunk[] is their exclusive prefix, chunk_clip[] maps a chunk back to its clip, n_seg_out[2] counts them.
+// chunk_rec[] holds one record per chunk, clip after clip, n_seg_out[2] counts them.
 __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__ off, int64_t n_clips, int L, int hop,
                                                      int64_t seg_cap, int64_t total, int64_t* __restrict__ clip_seg,
                                                      int64_t* __restrict__ seg_start, int* __restrict__ seg_valid, int* __restrict__ n_seg_out,
                                                      int share_T, int share_H, int64_t chunk_cap,
-                                                     int64_t* __restrict__ clip_chunk, int* __restrict__ chunk_clip) {
+                                                     ChunkRec* __restrict__ chunk_rec) {
     __shared__ long long s_wave[16];
     __shared__ long long s_carry, s_carry_c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -622,9 +630,12 @@ __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__
             for (int w = 0; w < wave; ++w) basec += s_wave[w];
             const long long firstc = basec + incc - nc;
             if (b < n_clips) {
-                clip_chunk[b] = firstc;
+                const long long last_valid = n - (S - 1) * hop;                      // samples of the clip's last segment
+                ChunkRec r;
+                r.beg = beg; r.seg0 = (int)first_seg; r.n_seg = (int)S;
+                r.avail = (int)((S - 1) * hop + (last_valid < 0 ? 0 : (last_valid > L ? L : last_valid)));
                 for (long long i = 0; i < nc; ++i)
-                    if (firstc + i < chunk_cap) chunk_clip[firstc + i] = (int)b;
+                    if (firstc + i < chunk_cap) { r.cidx = (int)i; chunk_rec[firstc + i] = r; }
             }
             __syncthreads();
             if (tid == 1023) s_carry_c = basec + incc;
@@ -636,10 +647,7 @@ __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__
         clip_seg[n_clips] = s_carry < seg_cap ? s_carry : seg_cap;
         n_seg_out[0] = (int)(s_carry < seg_cap ? s_carry : seg_cap);
         n_seg_out[1] = bad | (s_carry > seg_cap ? 4 : 0);
-        if (share_T > 0) {
-            clip_chunk[n_clips] = s_carry_c;
-            n_seg_out[2] = (int)(s_carry_c < chunk_cap ? s_carry_c : chunk_cap);
-        }
+        if (share_T > 0) n_seg_out[2] = (int)(s_carry_c < chunk_cap ? s_carry_c : chunk_cap);
     }
 }
 
@@ -684,8 +692,9 @@ struct radad_embed_s {
     float fb1[2] = {0.f, 0.f};
     int64_t plan_nchunks = 0;            // interior chunks of the cached plan (host-sized plans), or their upper bound (device-sized)
     bool plan_has_chunks = false;        // the cached plan carries the chunk arrays
-    DevBuf seg_stats, chunk_clip, clip_chunk;
+    DevBuf seg_stats, chunk_rec;
     int last_logmel_kind = 0;            // 0 per segment, 1 shared clip frames (radad_embed_last_logmel_kind)
+    int n_cus = 256;                     // compute units of the device (two chunk workgroups run on each)
     int* levels_dev = nullptr;
     // plan cache + scratch
     std::vector<int64_t> plan_key;       // the clip_offsets the cached plan was built from
@@ -730,13 +739,10 @@ static int plan_on_device(radad_embed_t h, const int64_t* clip_off_dev, int64_t 
     if ((rc = h->seg_valid.ensure((size_t)seg_cap * sizeof(int32_t)))) return rc;
     if ((rc = h->clip_seg.ensure((size_t)(n_clips + 1) * sizeof(int64_t)))) return rc;
     if ((rc = h->n_seg_dev.ensure(4 * sizeof(int)))) return rc;
-    if (chunk_cap > 0) {
-        if ((rc = h->chunk_clip.ensure((size_t)chunk_cap * sizeof(int)))) return rc;
-        if ((rc = h->clip_chunk.ensure((size_t)(n_clips + 1) * sizeof(int64_t)))) return rc;
-    }
+    if (chunk_cap > 0 && (rc = h->chunk_rec.ensure((size_t)chunk_cap * sizeof(ChunkRec)))) return rc;
     hipLaunchKernelGGL(k_build_plan, dim3(1), dim3(1024), 0, st, clip_off_dev, n_clips, h->cfg.segment_length, h->cfg.hop_length,
                        seg_cap, total, (int64_t*)h->clip_seg.p, (int64_t*)h->seg_start.p, (int*)h->seg_valid.p, (int*)h->n_seg_dev.p,
-                       chunk_cap > 0 ? h->nf : 0, h->share_H, chunk_cap, (int64_t*)h->clip_chunk.p, (int*)h->chunk_clip.p);
+                       chunk_cap > 0 ? h->nf : 0, h->share_H, chunk_cap, (ChunkRec*)h->chunk_rec.p);
     RADAD_HIP_CHECK(hipGetLastError());
     h->plan_has_chunks = chunk_cap > 0;
     h->plan_nchunks = chunk_cap;
@@ -822,7 +828,7 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.seg_len = h->cfg.segment_length; p.normalize = h->cfg.normalize; p.padded = h->padded; p.nf = h->nf;
     p.basis = h->basis; p.basis_h = h->basis_h; p.fbfrag = h->fbfrag; p.nzmask = h->nzmask; p.logmel = (float*)h->logmel.p;
     p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out; p.n_seg_dev = n_seg_dev;
-    p.seg_stats = nullptr; p.clip_seg = nullptr; p.chunk_clip = nullptr; p.clip_chunk = nullptr;
+    p.seg_stats = nullptr; p.clip_seg = nullptr; p.chunk_rec = nullptr; p.prefetch_dist = 0;
     p.seg_hop = 0; p.seg_hop_frames = 0; p.chunk_cap = 0; p.n_chunks = 0; p.fb1[0] = p.fb1[1] = 0.f;
     p.debug = 0;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (tools/exp_logmel.sh builds with -DRADAD_DEBUG_HOOKS); never in the shipped library
@@ -843,8 +849,8 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
                                (int)n_seg, n_seg_dev, (float*)h->seg_stats.p);
         p.seg_stats = (const float*)h->seg_stats.p;
         p.clip_seg = (const int64_t*)h->clip_seg.p;
-        p.chunk_clip = (const int*)h->chunk_clip.p;
-        p.clip_chunk = (const int64_t*)h->clip_chunk.p;
+        p.chunk_rec = (const ChunkRec*)h->chunk_rec.p;
+        p.prefetch_dist = 2 * h->n_cus;
         p.seg_hop = h->cfg.hop_length;
         p.seg_hop_frames = h->share_H;
         p.chunk_cap = (int)h->plan_nchunks;
@@ -909,6 +915,7 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
     if (!h) { radad_set_error("out of host memory"); return RADAD_ENOMEM; }
     h->cfg = *cfg; h->device = device; h->nbins = nbins; h->T = T; h->nf = nf; h->padded = padded;
     DeviceGuard g(device);
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus; }
 
     // folded, windowed DFT basis in MFMA fragment order
     std::vector<float> basis((size_t)NBT * NKK * 2 * 64 * 4);
@@ -1075,7 +1082,7 @@ int radad_embed_destroy(radad_embed_t h) {
         if (h->levels_dev) (void)hipFree(h->levels_dev);
         h->seg_start.release(); h->seg_valid.release(); h->clip_seg.release(); h->logmel.release(); h->seg_max.release();
         h->seg_pool.release(); h->clip_off.release(); h->n_seg_dev.release();
-        h->seg_stats.release(); h->chunk_clip.release(); h->clip_chunk.release();
+        h->seg_stats.release(); h->chunk_rec.release();
         for (int i = 0; i < 2; ++i) {
             if (h->pin[i]) (void)hipHostFree(h->pin[i]);
             if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
