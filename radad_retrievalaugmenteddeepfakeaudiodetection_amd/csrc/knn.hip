@@ -2532,7 +2532,16 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         knn_geometry_wide(h->ntotal, nq, &wq, &ws, &wc);
         // the sample pre-pass: one tile per workgroup, at most KW_SAMPLE_SPLITS tiles and 1/8 of the store (whatever the number of
         // query tiles: every phase of the scan is sized from the sample, a small sample means more phases)
-        s_splits = (int)std::min<int64_t>(KW_SAMPLE_SPLITS, h->ntotal / (8 * KW_M)) / 8 * 8;
+        // ... and about 3 % of it: the pre-pass multiplies every query tile with its rows, so on a shard of a row-sharded store -- 1/G of
+        // the rows against G times the queries -- a fixed 16 384-row sample was 12 % of the scan's own work at G = 8 (0.16 of 1.7 ms);
+        // large enough, though, for the floor's rank to exist twice over (16 entries per sample tile)
+        {
+            const int64_t tiles = h->ntotal / KW_M;
+            int64_t want = (tiles * 3 / 100 + 4) / 8 * 8;
+            const int64_t need = ((int64_t)(2 * ksel + KW_SAMPLE_LIST - 1) / KW_SAMPLE_LIST + 7) / 8 * 8;
+            want = std::max<int64_t>(std::max<int64_t>(want, need), 8);
+            s_splits = (int)std::min<int64_t>(std::min<int64_t>(KW_SAMPLE_SPLITS, want), tiles / 8 / 8 * 8);
+        }
         if (s_splits >= 8 && s_splits * KW_SAMPLE_LIST >= 2 * ksel) {
             if (h->hi_skip > 0) { --h->hi_skip; skipped_hi = true; }
             else if (knn_ensure_hi(h, st, true)) { use_hi = true; n_qtiles = wq; }
