@@ -821,8 +821,10 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     if ((rc = h->logmel.ensure((size_t)n_seg * h->nf * N_MELS * sizeof(float)))) return rc;
     if ((rc = h->seg_max.ensure((size_t)n_seg * sizeof(float)))) return rc;
     const float init = h->T > h->nf ? -10.f : -INFINITY;   // padded mode: silence frames take part in the max
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)std::min<int64_t>(1024, ceil_div64(n_seg, 256))), dim3(256), 0, st,
-                       (float*)h->seg_max.p, init, n_seg);
+    const bool clip_frames = h->share_frames && h->plan_has_chunks && !h->logmel_f32 && !norm_out;
+    if (!(clip_frames && h->cfg.normalize))                // (k_seg_stats starts the segment maxima itself)
+        hipLaunchKernelGGL(k_fill, dim3((unsigned)std::min<int64_t>(1024, ceil_div64(n_seg, 256))), dim3(256), 0, st,
+                           (float*)h->seg_max.p, init, n_seg);
     LogmelParams p;
     p.wave = wave_dev; p.seg_start = (const int64_t*)h->seg_start.p; p.seg_valid = (const int*)h->seg_valid.p;
     p.seg_len = h->cfg.segment_length; p.normalize = h->cfg.normalize; p.padded = h->padded; p.nf = h->nf;
@@ -839,14 +841,13 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.n_seg = (int)n_seg;
     const int wg_frames = std::max(p.split_f0, h->nf - p.split_f0);
     p.plane_halfs = lh_plane_halfs(wg_frames);
-    const bool clip_frames = h->share_frames && h->plan_has_chunks && !h->logmel_f32 && !norm_out;
     h->last_logmel_kind = clip_frames ? 1 : 0;
     if (clip_frames) {
         // the segments' statistics first (the transform is shared, the normalisation is not), then chunks and edge frames in one grid
         if ((rc = h->seg_stats.ensure((size_t)n_seg * 4 * sizeof(float)))) return rc;
         if (h->cfg.normalize)
             hipLaunchKernelGGL(k_seg_stats, dim3((unsigned)n_seg), dim3(LH_THREADS), 0, st, wave_dev, p.seg_start, p.seg_valid, p.seg_len,
-                               (int)n_seg, n_seg_dev, (float*)h->seg_stats.p);
+                               (int)n_seg, n_seg_dev, (float*)h->seg_stats.p, (float*)h->seg_max.p, init);
         p.seg_stats = (const float*)h->seg_stats.p;
         p.clip_seg = (const int64_t*)h->clip_seg.p;
         p.chunk_rec = (const ChunkRec*)h->chunk_rec.p;
