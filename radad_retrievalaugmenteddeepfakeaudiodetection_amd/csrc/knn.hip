@@ -1587,7 +1587,8 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
 // of `group` (<= 8) queries each.  A wave reads one row per step (coalesced), every lane multiplies its elements with
 // the group's queries from LDS in float64, a butterfly sum leaves the (row, query) scores in all lanes; each wave keeps
 // its exact top-k per query as a sorted LDS list (wave-cooperative insertion), the workgroup merges its waves' lists
-// and writes one list per (query slot, slice).  k_exact_merge then merges the slices and overwrites the query's results.
+// and writes one list per (query slot, slice); the slice that arrives last for a query group merges the slices (exact_merge_slot)
+// and overwrites the queries' results.
 // Keys are "larger is better" doubles (inner product, or minus the squared distance); order (key desc, id asc).
 constexpr int KX_THREADS = 512;
 constexpr int KX_WAVES = KX_THREADS / 64;
@@ -1605,14 +1606,18 @@ struct ExactParams {
     int* pidx;
     int64_t id_base;
     float* out_dist; int64_t* out_idx; double* out_key;
-    int* host_stats;           // pinned host memory (device-visible): k_exact_merge leaves the search's 6 counters there
+    int* host_stats;           // pinned host memory (device-visible): the kernel leaves the search's 6 counters there
+    int* arrive;               // [query groups] arrival counters of the slices (zero between launches: the last arrival resets its own)
 };
 
 __device__ __forceinline__ bool kx_better(double ka, int ia, double kb, int ib) { return ka > kb || (ka == kb && ia < ib); }
+__device__ __forceinline__ void exact_merge_slot(const ExactParams& p, int slot, int lane);
 
 __global__ __launch_bounds__(KX_THREADS) void k_exact_scan(ExactParams p) {
     const int count = *p.count;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 6 && p.host_stats) p.host_stats[threadIdx.x] = p.count[threadIdx.x];   // count + 5 statistics
     if (count <= 0) return;
+    __shared__ int s_last;
     extern __shared__ __attribute__((aligned(16))) char smem_x[];
     const int G = p.group;
     float* sQ = reinterpret_cast<float*>(smem_x);                                   // [G][dim]
@@ -1709,17 +1714,27 @@ __global__ __launch_bounds__(KX_THREADS) void k_exact_scan(ExactParams p) {
                 }
             }
         }
+        // the slice that arrives LAST for this query group merges the group's KX_SLICES partial lists (it used to be a second launch --
+        // and the usual search, with nothing rejected, paid two empty launches and the gap between them)
+        __threadfence();                                 // release: this slice's lists are visible device-wide before the counter moves
+        __syncthreads();
+        if (tid == 0) {
+            const int old = atomicAdd(&p.arrive[g], 1);
+            s_last = old == KX_SLICES - 1;
+            if (s_last) p.arrive[g] = 0;                 // ready for the next launch
+        }
+        __syncthreads();
+        if (s_last) {                                    // (workgroup-uniform)
+            __threadfence();                             // acquire
+            if (wave < ng) exact_merge_slot(p, g * G + wave, lane);
+        }
     }
 }
 
-// one wave per rejected query: merge its KX_SLICES partial lists, overwrite the query's output rows
-__global__ __launch_bounds__(256) void k_exact_merge(ExactParams p) {
-    const int count = *p.count;
-    if (blockIdx.x == 0 && threadIdx.x < 6 && p.host_stats) p.host_stats[threadIdx.x] = p.count[threadIdx.x];   // count + 5 statistics
-    const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slot >= count) return;
+// one wave: merge the KX_SLICES partial lists of rejected-query slot `slot`, overwrite the query's output rows
+__device__ __forceinline__ void exact_merge_slot(const ExactParams& p, int slot, int lane) {
     static_assert(KX_SLICES == 64, "one list per lane");
+    {
     const int64_t q = p.sel[slot];
     const double* lk = p.pkey + ((int64_t)slot * KX_SLICES + lane) * p.k;
     const int* li = p.pidx + ((int64_t)slot * KX_SLICES + lane) * p.k;
@@ -1742,6 +1757,7 @@ __global__ __launch_bounds__(256) void k_exact_merge(ExactParams p) {
             p.out_idx[q * p.k + o] = none ? -1 : (int64_t)bi + p.id_base;
             if (p.out_key) p.out_key[q * p.k + o] = d;
         }
+    }
     }
 }
 
@@ -2006,6 +2022,8 @@ struct radad_knn_s {
     float* kacc = nullptr;       // K-split tile scan (small stores of wide rows): partial accumulators of the two halves of a tile ...
     int* kflag = nullptr;        // ... and the arrival counters (zero between launches)
     int64_t kacc_tiles = 0;
+    int* xarrive = nullptr;      // exact pass: arrival counters of the query groups (zero between launches)
+    int64_t xarrive_cap = 0;
     int uniform_e = HI_E_PER_ROW; // one power-of-two scale 2^e for every row of the plane (rows of one magnitude), or HI_E_PER_ROW
     // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
     // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
@@ -2327,6 +2345,7 @@ int radad_knn_destroy(radad_knn_t h) {
         if (h->stat) (void)hipFree(h->stat);
         if (h->kacc) (void)hipFree(h->kacc);
         if (h->kflag) (void)hipFree(h->kflag);
+        if (h->xarrive) (void)hipFree(h->xarrive);
         if (h->host_count) (void)hipHostFree(h->host_count);
         for (int i = 0; i < 2; ++i) if (h->ev_count[i]) (void)hipEventDestroy(h->ev_count[i]);
         if (h->ev_done) (void)hipEventDestroy(h->ev_done);
@@ -2946,10 +2965,24 @@ static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* glo
         const size_t xlds = (size_t)c.xgroup * h->dim * 4 + (size_t)KX_WAVES * c.xgroup * k * 12 + 16;
         RADAD_REQUIRE(xlds <= 160 * 1024, "radad_knn_search: dim %d x k %d too large for the exact kernel", h->dim, k);
         RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_exact_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
+        if (nq > h->xarrive_cap) {                       // arrival counters of the query groups (zero between launches)
+            RADAD_HIP_CHECK(hipStreamSynchronize(st));
+            if (h->xarrive) (void)hipFree(h->xarrive);
+            h->xarrive = nullptr; h->xarrive_cap = 0;
+            const int64_t cap = nq + nq / 2 + 64;
+            if (hipMalloc((void**)&h->xarrive, (size_t)cap * sizeof(int)) != hipSuccess || hipMemset(h->xarrive, 0, (size_t)cap * sizeof(int)) != hipSuccess) {
+                (void)hipGetLastError();
+                if (h->xarrive) (void)hipFree(h->xarrive);
+                h->xarrive = nullptr;
+                radad_set_error("hipMalloc of the exact pass's arrival counters failed");
+                return RADAD_ENOMEM;
+            }
+            h->xarrive_cap = cap;
+        }
+        x.arrive = h->xarrive;
         hipLaunchKernelGGL(k_exact_scan, dim3(KX_SLICES, KX_GROUPS_Y), dim3(KX_THREADS), xlds, st, x);
-        hipLaunchKernelGGL(k_exact_merge, dim3((unsigned)ceil_div64(nq, 4)), dim3(256), 0, st, x);
         RADAD_HIP_CHECK(hipGetLastError());
-        RADAD_HIP_CHECK(hipEventRecord(h->ev_count[c.cslot], st));      // (k_exact_merge has written the counters to the pinned host copy)
+        RADAD_HIP_CHECK(hipEventRecord(h->ev_count[c.cslot], st));      // (k_exact_scan has written the counters to the pinned host copy)
         h->count_pending[c.cslot] = true;
         h->count_nq[c.cslot] = nq;
         ++h->search_seq;
