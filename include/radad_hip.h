@@ -294,6 +294,12 @@ int radad_embed_plan_flags(radad_embed_t h, int* flags_out);
  * configuration -- segment hop a multiple of 160 samples and smaller than the segment, Slaney filter bank -- for calls that hand over
  * clips; RADAD_LOGMEL_SHARED=0 turns it off).  Both give feature_extraction_whisper.py:135-168 per zero-mean/unit-variance segment. */
 int radad_embed_last_logmel_kind(radad_embed_t h, int* kind_out);
+/* How k_logmel_h_clip cuts a clip of n_segments segments (frames_per_segment frames each, segment hop = hop_frames frames) into
+ * workgroup chunks -- host arithmetic only, no device needed (the kernel, the plan kernel and the host share it): out5 = { full
+ * chunks of 104 interior frames, interior frames of the tail chunk, edge frames the tail chunk carries, edge-only chunks of <= 32
+ * edge frames, total chunks }.  The clip has (n_segments - 1) hop_frames + frames_per_segment - 3 interior frames and
+ * 3 n_segments edge frames (a segment's frames 0, 1 and T - 1). */
+int radad_embed_clip_chunks(int n_segments, int frames_per_segment, int hop_frames, int32_t* out5);
 
 /* same HIP-event timing for the two embedding kernels (k_logmel, k_proj_pool) of radad_embed_forward */
 int radad_embed_profile(radad_embed_t h, int enable);

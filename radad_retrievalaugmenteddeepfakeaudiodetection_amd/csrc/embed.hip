@@ -1203,6 +1203,14 @@ int radad_embed_plan_flags(radad_embed_t h, int* flags_out) {
     return RADAD_OK;
 }
 
+int radad_embed_clip_chunks(int n_segments, int frames_per_segment, int hop_frames, int32_t* out5) {
+    RADAD_REQUIRE(out5 && n_segments >= 0 && frames_per_segment >= 8 && hop_frames >= 1, "radad_embed_clip_chunks: bad argument");
+    const ClipChunks c = clip_chunking(n_segments, frames_per_segment, hop_frames);
+    out5[0] = c.n_full; out5[1] = c.r; out5[2] = c.e_tail; out5[3] = c.n_edge_chunks;
+    out5[4] = clip_chunk_count(n_segments, frames_per_segment, hop_frames);
+    return RADAD_OK;
+}
+
 int radad_embed_last_logmel_kind(radad_embed_t h, int* kind_out) {
     RADAD_REQUIRE(h && kind_out, "radad_embed_last_logmel_kind: NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);

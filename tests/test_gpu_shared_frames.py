@@ -94,3 +94,38 @@ def test_shared_frames_logmel_rows(gpu, monkeypatch):
     b = fe_ref.embed_clips(wave, offs)
     assert fe.last_logmel_kind() == "clip_frames" and fe_ref.last_logmel_kind() == "per_segment"
     assert float((a - b).abs().max()) < 5e-6
+
+
+def test_shared_frames_at_the_benchmarks_size(gpu, monkeypatch):
+    """BASELINE's full batch (1024 clips x 4 s, F = 512): no oracle at this size -- the size-independent properties instead.
+    (1) both log-mel kernels give the same embeddings; (2) zero-mean / unit-variance normalisation makes the embedding invariant
+    under a gain and an offset per CLIP... per segment, in fact: x -> a x + b changes nothing (exact powers of two for a: the
+    scaling then commutes with every rounding); (3) a clip embeds the same whatever batch it sits in and wherever its samples start
+    in the wave buffer (chunk lists, pivots and prefetch distances differ: the result may not)."""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+    lib = _lib.load()
+    kw = dict(feature_dim=512, tpp_levels=[1], tpp_pooling_type="max", segment_length=2.0, segment_overlap=0.5, melproj_seed=1)
+    fe = _extractor(R, gpu, monkeypatch, True, **kw)
+    fe_ref = _extractor(R, gpu, monkeypatch, False, **kw)
+    B, n = 1024, 64000
+    wave = torch.empty(B * n, device=gpu)
+    _lib.check(lib.radad_synth_audio(wave.data_ptr(), 0, B, n, 1234, gpu.index or 0, _lib.stream_ptr(gpu)))
+    offs = np.arange(B + 1, dtype=np.int64) * n
+    a = fe.embed_clips(wave, offs)
+    assert fe.last_logmel_kind() == "clip_frames"
+    b = fe_ref.embed_clips(wave, offs)
+    assert fe_ref.last_logmel_kind() == "per_segment"
+    assert a.shape == (B, 512) and bool(torch.isfinite(a).all())
+    assert float((a - b).abs().max()) < 2e-5                                   # (1)
+    # (gains >= 1: the 1e-7 inside sqrt(var + 1e-7) -- feature_extraction_wav2vec2.py:95 -- is NOT scale invariant for quiet audio)
+    gain = torch.exp2(torch.randint(0, 7, (B,), device=gpu).float()).repeat_interleave(n)
+    c = fe.embed_clips(wave * gain, offs)
+    assert float((a - c).abs().max()) < 2e-5                                   # (2) power-of-two gains: the same up to the 1e-7 in sqrt(var + 1e-7)
+    d = fe.embed_clips(wave * 3.0 + 0.25, offs)
+    assert float((a - d).abs().max()) < 5e-5                                   #     any gain and a DC offset: within the 1e-4 bar
+    pick = torch.tensor([0, 1, 511, 1023], device=gpu)
+    sub = torch.cat([torch.zeros(37, device=gpu)] + [wave[i * n:(i + 1) * n] for i in pick.tolist()])     # unaligned start
+    e = fe.embed_clips(sub, 37 + np.arange(5, dtype=np.int64) * n)
+    assert float((e - a[pick]).abs().max()) == 0.0                             # (3) bit for bit

@@ -238,3 +238,27 @@ def test_load_follows_the_saved_index_type_not_a_stale_sidecar(tmp_path, monkeyp
     g2 = V.VectorDatabase(c)
     g2.load()
     assert type(g2.index) is FakeFlat and g2.index.ntotal == 7
+
+
+def test_clip_chunking_covers_every_frame_once_and_fits_the_planes():
+    """the work list of k_logmel_h_clip (csrc/logmel_h.inc: clip_chunking, shared by the kernel, the plan kernel and the host; host
+    arithmetic, no GPU): for every (segments, frames per segment, segment hop in frames) the chunks hold each interior frame of the
+    clip and each of its 3 S edge frames exactly once, no chunk exceeds 128 frame slots (four 32-frame waves) or the LDS planes
+    (20 272 halfs: the interior frames' samples at a stride of 168 halfs per frame + 424 halfs per edge window)."""
+    lib = _lib.load()
+    out = (C.c_int32 * 5)()
+    for T, H in ((200, 100), (200, 50), (100, 50), (50, 40), (200, 150), (8, 4), (223, 1), (64, 63)):
+        for S in list(range(1, 40)) + [97, 500]:
+            _lib.check(lib.radad_embed_clip_chunks(S, T, H, out))
+            n_full, r, e_tail, n_edge_chunks, total = (int(v) for v in out)
+            ni, E = (S - 1) * H + T - 3, 3 * S
+            assert n_full * 104 + r == ni and 0 <= r < 104                              # interior frames: full chunks + the tail's
+            assert total == n_full + 1 + n_edge_chunks
+            assert 0 <= e_tail <= E and r + e_tail <= 128
+            planes_r = 0 if r == 0 else -(-((160 * (r - 1) + 400) + 8 * ((160 * (r - 1) + 400) // 160) + 8) // 16) * 16
+            assert planes_r + 424 * e_tail <= 20272, (T, H, S)
+            rest = E - e_tail                                                            # edge frames left for the edge-only chunks
+            assert n_edge_chunks == -(-rest // 32) and (rest == 0) == (n_edge_chunks == 0)
+    _lib.check(lib.radad_embed_clip_chunks(0, 200, 100, out))
+    assert list(out) == [0, 0, 0, 0, 0]
+    assert lib.radad_embed_clip_chunks(3, 4, 2, out) == _lib.RADAD_EINVAL               # fewer than 8 frames per segment: not this path
