@@ -163,3 +163,48 @@ def test_fuzz_scan_phases_and_planes(gpu, knn_oracle_lib, seed):
             assert np.array_equal(I_s, oi), what
         np.testing.assert_allclose(K64[sample].cpu().numpy(), od, rtol=1e-9, atol=1e-9, err_msg=str(what))
         del idx, rows, stored
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_fuzz_embed_shared_frames(gpu, seed):
+    """the shared-frame log-mel kernel (k_logmel_h_clip) under random segment shapes: T = 8 .. 200 frames per segment, segment hops
+    of 2 .. 150 frames with one to four owners per frame, clips from shorter than a segment (zero padded) to dozens of segments
+    (edge-only chunks), all pooling options; against the numpy float64 oracle, host- and device-resident offsets bit for bit."""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    rng = np.random.default_rng(seed)
+    shapes = [(8, 2), (8, 4), (10, 5), (24, 8), (40, 10), (40, 30), (100, 25), (100, 50), (100, 75), (200, 50), (200, 100), (200, 150)]
+    for case in range(8):
+        T, H = shapes[rng.integers(len(shapes))]
+        L, hop = 160 * T, 160 * H
+        F = int(rng.choice([32, 64, 256]))
+        levels = [[1], [1, 2], [1, 2, 4], [3]][rng.integers(4)]
+        mode = ["max", "avg"][rng.integers(2)]
+        norm = bool(rng.integers(4) != 0)
+        cfg = R.Config()
+        cfg.update(device=gpu, feature_dim=F, tpp_levels=levels, tpp_pooling_type=mode, segment_length=L / 16000,
+                   segment_overlap=1.0 - (hop + 0.25) / L,               # (the mirror takes int(L (1 - overlap)) like the reference)
+                   melproj_normalize=norm, melproj_seed=300 + 10 * seed + case)
+        fe = R.MelProjectionFeatureExtractor(cfg)
+        assert (fe.segment_length, fe.hop_length) == (L, hop), (T, H, fe.segment_length, fe.hop_length)
+        nclip = int(rng.integers(1, 5))
+        budget = 150000                                                   # samples per clip at most (the oracle is numpy float64)
+        lens = [int(x) for x in rng.choice([L // 2 + 3, L, L + 1, L + hop, L + 3 * hop + 77, min(budget, L + 40 * hop + 5)], size=nclip)]
+        gain = np.float32(rng.choice([1.0, 1e-3, 50.0]))
+        wav = synth.audio(0, nclip, max(lens), 8000 + 100 * seed + case) * gain
+        if rng.integers(2):
+            # a DC offset of the signal's own order: the mean correction of bands 0 and 1.  (Not 0.3 beside an amplitude of 1e-3: the
+            # segment statistics are float32 two-pass sums, as HF's float32 numpy arrays give the reference -- with the mean 1500 x the
+            # standard deviation that alone moves an embedding by 5.6e-4 against this float64 oracle, in the per-segment kernel too.)
+            wav += np.float32(0.3) * gain
+        clips = [wav[i, :n] for i, n in enumerate(lens)]
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        wave = torch.from_numpy(np.concatenate(clips)).to(gpu)
+        emb = fe.embed_clips(wave, offs)
+        what = dict(seed=seed, case=case, T=T, H=H, F=F, levels=levels, mode=mode, norm=norm, lens=lens)
+        assert fe.last_logmel_kind() == "clip_frames", what
+        emb_dev = fe.embed_clips(wave, torch.from_numpy(offs).to(gpu))
+        ref = O.embed_clips(clips, L, hop, fe.proj_w, fe.proj_b, tuple(levels), mode, normalize=norm)
+        err = float(np.abs(emb.cpu().numpy() - ref).max())
+        assert emb.shape == ref.shape and err < 1e-4, dict(what, err=err)
+        assert torch.equal(emb, emb_dev), what
