@@ -77,8 +77,8 @@ def scan_traffic_from_profiles(section):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (0.2 s at the default workload)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--clips", type=int, default=CLIPS_PER_GPU, help="clips per GPU per step")
     ap.add_argument("--db-rows", type=int, default=DB_ROWS, help="total reference-store rows")
     ap.add_argument("--cpu-sample", type=int, default=192, help="clips checked against the float64 oracle (0 = skip the check)")
