@@ -290,9 +290,11 @@ int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_
  * value means the embeddings of that batch are NOT those of the intended clips. */
 int radad_embed_plan_flags(radad_embed_t h, int* flags_out);
 /* Which log-mel kernel the most recent embedding call took: 0 = one transform per (segment, frame) (k_logmel_h, or k_logmel under
- * RADAD_LOGMEL_F32); 1 = the frames overlapping segments share were transformed once per CLIP (k_logmel_h_clip: chosen by the
- * configuration -- segment hop a multiple of 160 samples and smaller than the segment, Slaney filter bank -- for calls that hand over
- * clips; RADAD_LOGMEL_SHARED=0 turns it off).  Both give feature_extraction_whisper.py:135-168 per zero-mean/unit-variance segment. */
+ * RADAD_LOGMEL_F32); 1, 2 = the frames overlapping segments share were transformed once per CLIP (chosen by the configuration --
+ * segment hop a multiple of 160 samples and smaller than the segment, Slaney filter bank -- for calls that hand over clips;
+ * RADAD_LOGMEL_SHARED=0 turns it off): 2 = as a radix FFT on the vector ALU (k_logmel_fft_clip, the default), 1 = as a DFT-as-GEMM on
+ * the f16 matrix pipe (k_logmel_h_clip: RADAD_LOGMEL_FFT=0, or a filter bank that is not triangular).  All give
+ * feature_extraction_whisper.py:135-168 per zero-mean/unit-variance segment. */
 int radad_embed_last_logmel_kind(radad_embed_t h, int* kind_out);
 /* How k_logmel_h_clip cuts a clip of n_segments segments (frames_per_segment frames each, segment hop = hop_frames frames) into
  * workgroup chunks -- host arithmetic only, no device needed (the kernel, the plan kernel and the host share it): out5 = { full
@@ -300,6 +302,20 @@ int radad_embed_last_logmel_kind(radad_embed_t h, int* kind_out);
  * edge frames, total chunks }.  The clip has (n_segments - 1) hop_frames + frames_per_segment - 3 interior frames and
  * 3 n_segments edge frames (a segment's frames 0, 1 and T - 1). */
 int radad_embed_clip_chunks(int n_segments, int frames_per_segment, int hop_frames, int32_t* out5);
+/* The same for k_logmel_fft_clip (the shared-frame work list as a radix FFT on the vector ALU, csrc/logmel_fft.inc): chunks of 64
+ * frame slots; out5 = { full chunks of 64 interior frames, interior frames of the tail chunk, edge frames the tail chunk carries,
+ * edge-only chunks of <= 26 edge frames, total chunks }.  Host arithmetic only. */
+int radad_embed_fft_clip_chunks(int n_segments, int frames_per_segment, int hop_frames, int32_t* out5);
+/* The per-lane constant tables of k_logmel_fft_clip for a mel filter bank [201, 80] (host arithmetic only, no device needed;
+ * tests/test_fft_tables.py drives a numpy restatement of the kernel's data flow with them and compares it with numpy.fft.rfft and the
+ * oracle's log-mel).  tab_out must hold `cap` >= 2064 floats: 25 groups (index k1, or the sample group m for the window) of
+ * [hann(16 m + 2 r), hann(16 m + 2 r + 1)] [cos, sin of W200^(r k1)] [cos, sin of W400^k, k = 25 k2 + k1] [fb[k][b] / 4,
+ * fb[k][b + 1] / 4, 4 b as int32 bits, 0], each for the 8 lanes of an octet (lane p holds the residue class r = p < 4 ? p : 11 - p
+ * of the packed frame and ends with the bin block k2 = bitrev3(p)), then per lane the constants of the three exchange stages
+ * [g1, c1, s1, g2, c2, s2, g3, 0]: own <- (own + g partner)(c + i s).  info4 = { 1 if every bin of the bank feeds at most two
+ * adjacent bands (what the sparse mel step needs; otherwise the matrix-pipe kernels run), floats written, first band of bin 200,
+ * 1 if bin 200 carries weight }. */
+int radad_embed_fft_tables(const float* mel_filters_host, float* tab_out, int cap, int32_t* info4);
 
 /* same HIP-event timing for the two embedding kernels (k_logmel, k_proj_pool) of radad_embed_forward */
 int radad_embed_profile(radad_embed_t h, int enable);

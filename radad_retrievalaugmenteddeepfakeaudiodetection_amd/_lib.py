@@ -118,6 +118,8 @@ SIGNATURES = {
     "radad_embed_plan_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_embed_last_logmel_kind": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_embed_clip_chunks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "radad_embed_fft_clip_chunks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "radad_embed_fft_tables": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int32)]),
     "radad_embed_normalize": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, c_i32p, C.c_int64, C.c_void_p, C.c_void_p]),
     "radad_embed_logmel": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, c_i32p, C.c_int64, C.c_void_p, C.c_void_p]),
     "radad_embed_frame_features": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, c_i32p, C.c_int64, C.c_void_p,

@@ -103,6 +103,10 @@ struct LogmelParams {
     int chunk_cap;               // grid size: chunks (workgroups past the true count leave)
     int n_chunks;                // true count when the plan was sized on the host (else n_seg_dev[2])
     float fb1[2];                // filter-bank weights of bin 1 in mel bands 0 and 1
+    // k_logmel_fft_clip (the same work list on the vector ALU: logmel_fft.inc)
+    const float* fft_tab;        // [FC_TAB_FLOATS] lane tables (fc_build_tables)
+    float fb200[2];              // filter-bank weights of bin 200 in bands band200, band200 + 1 (zero in the Slaney bank)
+    int band200;
     int debug;                   // timing experiments only (RADAD_DEBUG_LOGMEL): 1 = skip the MFMA loop, 2 = skip the prologue
 };
 
@@ -288,6 +292,7 @@ __global__ __launch_bounds__(LM_THREADS, 2) void k_logmel(LogmelParams p) {
 }
 
 #include "logmel_h.inc"
+#include "logmel_fft.inc"
 
 // ---- projection + pooling -----------------------------------------------------------------------------
 // WAVES x 32 features per workgroup: 16 waves (all 512 features of the benchmark: each segment's log-mel is staged once
@@ -559,13 +564,13 @@ __global__ __launch_bounds__(256) void k_group_mean(const float* __restrict__ in
 // -1: unknown, only negative lengths are repaired) and the segment count to seg_cap, so that whatever the tensor holds the kernels
 // behind this one read inside the wave buffer and inside their own scratch.  n_seg_out[1] reports what had to be repaired:
 // bit 0 an offset outside [0, total], bit 1 a clip ending before it starts, bit 2 more segments than seg_cap.
-// Chunk plan of k_logmel_h_clip (share_T > 0): a clip of S segments is cut into clip_chunk_count(S, T, H) chunks (logmel_h.inc);
-// chunk_rec[] holds one record per chunk, clip after clip, n_seg_out[2] counts them.
+// Chunk plan of k_logmel_h_clip / k_logmel_fft_clip (share_T > 0): a clip of S segments is cut into chunk_count_g(geom, S, T, H)
+// chunks (logmel_h.inc, logmel_fft.inc); chunk_rec[] holds one record per chunk, clip after clip, n_seg_out[2] counts them.
 __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__ off, int64_t n_clips, int L, int hop,
                                                      int64_t seg_cap, int64_t total, int64_t* __restrict__ clip_seg,
                                                      int64_t* __restrict__ seg_start, int* __restrict__ seg_valid, int* __restrict__ n_seg_out,
                                                      int share_T, int share_H, int64_t chunk_cap,
-                                                     ChunkRec* __restrict__ chunk_rec) {
+                                                     ChunkRec* __restrict__ chunk_rec, int geom) {
     __shared__ long long s_wave[16];
     __shared__ long long s_carry, s_carry_c;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -617,7 +622,7 @@ __global__ __launch_bounds__(1024) void k_build_plan(const int64_t* __restrict__
         if (share_T > 0) {                               // the same scan over the clips' chunk counts
             const long long first_seg = first < seg_cap ? first : seg_cap;
             const long long S = (b < n_clips) ? ((first + ns < seg_cap ? first + ns : seg_cap) - first_seg) : 0;     // segments that made it into the plan
-            const long long nc = clip_chunk_count((int)S, share_T, share_H);
+            const long long nc = chunk_count_g(geom, (int)S, share_T, share_H);
             long long incc = nc;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -673,6 +678,82 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
+
+// Lane tables of k_logmel_fft_clip (layout: logmel_fft.inc; data flow checked in numpy by tools/fft_design.py and, driven by THESE
+// tables, by tests/test_fft_tables.py).  Lane pl of an octet holds the residue class rr = pl < 4 ? pl : 11 - pl of the packed
+// frame and ends with the bin block k2 = bitrev3(pl).  Returns false when a bin of the filter bank feeds bands that are not two
+// adjacent ones (the sparse mel step cannot express that: the matrix-pipe kernels stay).
+static bool fc_build_tables(const float* fb /* [201][80] */, float* tab /* [FC_TAB_FLOATS] */, float fb200[2], int* band200) {
+    const double PI = 3.14159265358979323846;
+    for (int i = 0; i < FC_TAB_FLOATS; ++i) tab[i] = 0.f;
+    auto bands_of = [&](int bin, int* b_out, float* wl, float* wh) -> bool {
+        int first = -1, last = -1;
+        for (int b = 0; b < N_MELS; ++b)
+            if (fb[bin * N_MELS + b] != 0.f) { if (first < 0) first = b; last = b; }
+        int b = first < 0 ? 0 : first;
+        if (first >= 0 && last - first > 1) return false;
+        if (b > N_MELS - 2) b = N_MELS - 2;
+        *b_out = b; *wl = fb[bin * N_MELS + b]; *wh = fb[bin * N_MELS + b + 1];
+        return true;
+    };
+    for (int pl = 0; pl < 8; ++pl) {
+        const int rr = pl < 4 ? pl : 11 - pl;
+        const int k2 = ((pl & 1) << 2) | (pl & 2) | ((pl >> 2) & 1);
+        for (int k1 = 0; k1 < 25; ++k1) {
+            float* t = tab + k1 * FC_TABK;
+            for (int e = 0; e < 2; ++e) {                                       // periodic hann at n = 16 m + 2 rr + e (m = k1's slot)
+                const int n = 16 * k1 + 2 * rr + e;
+                t[2 * pl + e] = (float)(0.5 - 0.5 * cos(2.0 * PI * n / N_FFT));
+            }
+            const int e200 = (rr * k1) % 200;                                   // W200^(rr k1) = cos - i sin
+            t[16 + 2 * pl] = (float)cos(2.0 * PI * e200 / 200.0);
+            t[16 + 2 * pl + 1] = (float)sin(2.0 * PI * e200 / 200.0);
+            const int k = 25 * k2 + k1;                                         // the bin this lane ends with at k1
+            t[32 + 2 * pl] = (float)cos(2.0 * PI * k / 400.0);
+            t[32 + 2 * pl + 1] = (float)sin(2.0 * PI * k / 400.0);
+            int b; float wl, wh;
+            if (!bands_of(k, &b, &wl, &wh)) return false;
+            t[48 + 4 * pl] = 0.25f * wl;                                        // the kernel forms 4 |X|^2
+            t[48 + 4 * pl + 1] = 0.25f * wh;
+            const int boff = 4 * b;
+            memcpy(&t[48 + 4 * pl + 2], &boff, sizeof(int));
+        }
+        // exchange stages: own <- (own + g partner)(c + i s).  Stage t pairs index i with i +- half inside the lane's branch; the lane
+        // whose bit (2, 1, 0) of pl is clear keeps the sum, the other (x_small - x_big) W8^e.  A stage without multiply (the third) cannot
+        // flip a sign, so lanes 1 and 3 -- which hold the larger index there and need partner - own -- get their stage-2 value negated.
+        float* net = tab + FC_NET + 8 * pl;
+        int idx = rr;
+        for (int stage = 0; stage < 3; ++stage) {
+            const int half = 4 >> stage, bit = 2 - stage;
+            const bool hi = (pl >> bit) & 1, small = idx < half;
+            const int e = (idx % half) * (4 / half);                            // twiddle exponent of W8
+            double g = 1.0, c = 1.0, sn = 0.0;
+            if (hi) {
+                g = -1.0;
+                const double sgn = small ? 1.0 : -1.0;
+                c = sgn * cos(2.0 * PI * e / 8.0);
+                sn = -sgn * sin(2.0 * PI * e / 8.0);
+            }
+            if (stage == 1 && (pl == 1 || pl == 3)) { c = -c; sn = -sn; }       // stored negated for stage 3
+            if (stage == 2) {
+                // inputs of lanes 1, 3 carry a minus sign: lane p < 4 odd wants partner - own = own' + partner; its partner own - own'
+                if (pl < 4) g = (pl & 1) ? 1.0 : -1.0;
+                else g = (pl & 1) ? -1.0 : 1.0;
+                net[6] = (float)g;
+            } else {
+                net[3 * stage] = (float)g;
+                net[3 * stage + 1] = (float)(fabs(c) < 1e-15 ? 0.0 : c);
+                net[3 * stage + 2] = (float)(fabs(sn) < 1e-15 ? 0.0 : sn);
+            }
+            idx %= half;
+        }
+    }
+    int b; float wl, wh;
+    if (!bands_of(N_BINS - 1, &b, &wl, &wh)) return false;
+    fb200[0] = wl; fb200[1] = wh; *band200 = b;
+    return true;
+}
+
 }  // namespace
 
 struct radad_embed_s {
@@ -690,6 +771,12 @@ struct radad_embed_s {
     int share_frames = 0;                // 1: batches given as clips take k_logmel_h_clip (RADAD_LOGMEL_SHARED=0 turns it off)
     int share_H = 0;                     // segment hop in frames
     float fb1[2] = {0.f, 0.f};
+    // k_logmel_fft_clip: the shared-frame work list as a radix FFT on the vector ALU (logmel_fft.inc).  Needs what share_frames needs
+    // and a filter bank whose bins feed at most two adjacent bands (triangular filters); RADAD_EMBED_DFT_GEMM keeps k_logmel_h_clip
+    int logmel_fft = 0;
+    float* fft_tab = nullptr;
+    float fb200[2] = {0.f, 0.f};
+    int band200 = 0;
     int64_t plan_nchunks = 0;            // interior chunks of the cached plan (host-sized plans), or their upper bound (device-sized)
     bool plan_has_chunks = false;        // the cached plan carries the chunk arrays
     DevBuf seg_stats, chunk_rec;
@@ -742,14 +829,14 @@ static int plan_on_device(radad_embed_t h, const int64_t* clip_off_dev, int64_t 
     if (chunk_cap > 0 && (rc = h->chunk_rec.ensure((size_t)chunk_cap * sizeof(ChunkRec)))) return rc;
     hipLaunchKernelGGL(k_build_plan, dim3(1), dim3(1024), 0, st, clip_off_dev, n_clips, h->cfg.segment_length, h->cfg.hop_length,
                        seg_cap, total, (int64_t*)h->clip_seg.p, (int64_t*)h->seg_start.p, (int*)h->seg_valid.p, (int*)h->n_seg_dev.p,
-                       chunk_cap > 0 ? h->nf : 0, h->share_H, chunk_cap, (ChunkRec*)h->chunk_rec.p);
+                       chunk_cap > 0 ? h->nf : 0, h->share_H, chunk_cap, (ChunkRec*)h->chunk_rec.p, h->logmel_fft ? 1 : 0);
     RADAD_HIP_CHECK(hipGetLastError());
     h->plan_has_chunks = chunk_cap > 0;
     h->plan_nchunks = chunk_cap;
     return RADAD_OK;
 }
 static int64_t clip_chunks(const radad_embed_s* h, int64_t n_segments_of_clip) {       // chunks of one clip
-    return clip_chunk_count((int)n_segments_of_clip, h->nf, h->share_H);
+    return chunk_count_g(h->logmel_fft ? 1 : 0, (int)n_segments_of_clip, h->nf, h->share_H);
 }
 
 // Plan for clip offsets in HOST memory (segmenter.py:25-39): the host only counts the segments (it needs the grid size);
@@ -832,6 +919,7 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out; p.n_seg_dev = n_seg_dev;
     p.seg_stats = nullptr; p.clip_seg = nullptr; p.chunk_rec = nullptr; p.prefetch_dist = 0;
     p.seg_hop = 0; p.seg_hop_frames = 0; p.chunk_cap = 0; p.n_chunks = 0; p.fb1[0] = p.fb1[1] = 0.f;
+    p.fft_tab = nullptr; p.fb200[0] = p.fb200[1] = 0.f; p.band200 = 0;
     p.debug = 0;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (tools/exp_logmel.sh builds with -DRADAD_DEBUG_HOOKS); never in the shipped library
     { const char* dbg = getenv("RADAD_DEBUG_LOGMEL"); p.debug = dbg ? atoi(dbg) : 0; }
@@ -841,7 +929,7 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.n_seg = (int)n_seg;
     const int wg_frames = std::max(p.split_f0, h->nf - p.split_f0);
     p.plane_halfs = lh_plane_halfs(wg_frames);
-    h->last_logmel_kind = clip_frames ? 1 : 0;
+    h->last_logmel_kind = clip_frames ? (h->logmel_fft ? 2 : 1) : 0;
     if (clip_frames) {
         // the segments' statistics first (the transform is shared, the normalisation is not), then chunks and edge frames in one grid
         if ((rc = h->seg_stats.ensure((size_t)n_seg * 4 * sizeof(float)))) return rc;
@@ -858,7 +946,11 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
         p.n_chunks = (int)h->plan_nchunks;
         p.fb1[0] = h->fb1[0]; p.fb1[1] = h->fb1[1];
         p.plane_halfs = LH_CLIP_PLANE_HALFS;
-        hipLaunchKernelGGL(k_logmel_h_clip, dim3((unsigned)h->plan_nchunks), dim3(LH_THREADS), logmel_h_clip_lds_bytes(), st, p);
+        p.fft_tab = h->fft_tab; p.fb200[0] = h->fb200[0]; p.fb200[1] = h->fb200[1]; p.band200 = h->band200;
+        if (h->logmel_fft)
+            hipLaunchKernelGGL(k_logmel_fft_clip, dim3((unsigned)h->plan_nchunks), dim3(FC_THREADS), logmel_fft_lds_bytes(), st, p);
+        else
+            hipLaunchKernelGGL(k_logmel_h_clip, dim3((unsigned)h->plan_nchunks), dim3(LH_THREADS), logmel_h_clip_lds_bytes(), st, p);
     } else if (h->logmel_f32) hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);
     else hipLaunchKernelGGL(k_logmel_h, dim3((unsigned)(16 * ((n_seg + 7) / 8))), dim3(LH_THREADS), logmel_h_lds_bytes(wg_frames), st, p);
     h->prof_logmel.end(st);
@@ -1041,7 +1133,16 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
         h->fb1[1] = mel_filters_host[1 * N_MELS + 1];
     }
     { const char* e = radad_env_override("RADAD_LOGMEL_F32", "non-zero selects the fp32-MFMA log-mel kernel (k_logmel, ~2x slower) for extractors created from now on"); h->logmel_f32 = (e && atoi(e) != 0) ? 1 : 0; }
+    std::vector<float> fft_tab(FC_TAB_FLOATS);
+    {
+        // the shared-frame work list as a radix FFT on the vector ALU whenever the configuration allows sharing and the filter bank is triangular
+        bool ok = h->share_frames && !h->logmel_f32 && fc_build_tables(mel_filters_host, fft_tab.data(), h->fb200, &h->band200);
+        const char* e = radad_env_override("RADAD_LOGMEL_FFT", "0 keeps the DFT-as-GEMM log-mel kernel (k_logmel_h_clip) instead of the radix FFT (k_logmel_fft_clip) for extractors created from now on");
+        if (e && atoi(e) == 0) ok = false;
+        h->logmel_fft = ok ? 1 : 0;
+    }
     int rc = put(&h->basis, basis.data(), basis.size() * sizeof(float));
+    if (!rc && h->logmel_fft) rc = put(&h->fft_tab, fft_tab.data(), fft_tab.size() * sizeof(float));
     if (!rc) rc = put((float**)&h->basis_h, basis_h.data(), basis_h.size() * sizeof(_Float16));
     if (!rc) rc = put(&h->fbfrag, fbfrag.data(), fbfrag.size() * sizeof(float));
     if (!rc) rc = put((float**)&h->wfrag_h, wfrag_h.data(), wfrag_h.size() * sizeof(_Float16));
@@ -1055,6 +1156,8 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
                                 (int)logmel_h_lds_bytes(LH_WG_FRAMES)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel_h_clip), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)logmel_h_clip_lds_bytes()) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel_fft_clip), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)logmel_fft_lds_bytes()) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)projpool_lds_bytes(8)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1076,6 +1179,7 @@ int radad_embed_destroy(radad_embed_t h) {
         DeviceGuard g(h->device);
         if (h->basis) (void)hipFree(h->basis);
         if (h->basis_h) (void)hipFree(h->basis_h);
+        if (h->fft_tab) (void)hipFree(h->fft_tab);
         if (h->fbfrag) (void)hipFree(h->fbfrag);
         if (h->wfrag_h) (void)hipFree(h->wfrag_h);
         if (h->wscale) (void)hipFree(h->wscale);
@@ -1171,8 +1275,9 @@ int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_
     const int64_t seg_cap = n_samples_total / h->cfg.hop_length + n_clips;
     RADAD_REQUIRE(seg_cap < (1ll << 31), "radad_embed_forward_dev: too many segments in one batch");
     // chunks: a clip of S segments has <= ((S - 1) H + T) / 96 + 1 + 3 S / 32 + 1 of them
-    const int64_t chunk_cap = h->share_frames ? (seg_cap * h->share_H + n_clips * h->nf) / LH_CLIP_FRAMES + (3 * seg_cap) / LH_EDGE_CHUNK +
-                                                    2 * n_clips + 1 : 0;
+    const int64_t chunk_cap = !h->share_frames ? 0
+                              : h->logmel_fft ? (seg_cap * h->share_H + n_clips * h->nf) / FC_SLOTS + (3 * seg_cap) / FC_EDGE_CHUNK + 2 * n_clips + 1
+                                              : (seg_cap * h->share_H + n_clips * h->nf) / LH_CLIP_FRAMES + (3 * seg_cap) / LH_EDGE_CHUNK + 2 * n_clips + 1;
     RADAD_REQUIRE(chunk_cap < (1ll << 30), "radad_embed_forward_dev: too many frames in one batch");
     int rc = plan_on_device(h, clip_offsets_dev, n_clips, seg_cap, n_samples_total, st, chunk_cap);
     if (rc) return rc;
@@ -1208,6 +1313,23 @@ int radad_embed_clip_chunks(int n_segments, int frames_per_segment, int hop_fram
     const ClipChunks c = clip_chunking(n_segments, frames_per_segment, hop_frames);
     out5[0] = c.n_full; out5[1] = c.r; out5[2] = c.e_tail; out5[3] = c.n_edge_chunks;
     out5[4] = clip_chunk_count(n_segments, frames_per_segment, hop_frames);
+    return RADAD_OK;
+}
+
+int radad_embed_fft_clip_chunks(int n_segments, int frames_per_segment, int hop_frames, int32_t* out5) {
+    RADAD_REQUIRE(out5 && n_segments >= 0 && frames_per_segment >= 8 && hop_frames >= 1, "radad_embed_fft_clip_chunks: bad argument");
+    const ClipChunks c = fc_chunking(n_segments, frames_per_segment, hop_frames);
+    out5[0] = c.n_full; out5[1] = c.r; out5[2] = c.e_tail; out5[3] = c.n_edge_chunks;
+    out5[4] = fc_chunk_count(n_segments, frames_per_segment, hop_frames);
+    return RADAD_OK;
+}
+
+int radad_embed_fft_tables(const float* mel_filters_host, float* tab_out, int cap, int32_t* info4) {
+    RADAD_REQUIRE(mel_filters_host && tab_out && info4 && cap >= FC_TAB_FLOATS, "radad_embed_fft_tables: bad argument (the table holds %d floats)", FC_TAB_FLOATS);
+    float fb200[2] = {0.f, 0.f};
+    int band200 = 0;
+    const bool ok = fc_build_tables(mel_filters_host, tab_out, fb200, &band200);
+    info4[0] = ok ? 1 : 0; info4[1] = FC_TAB_FLOATS; info4[2] = band200; info4[3] = (fb200[0] != 0.f || fb200[1] != 0.f) ? 1 : 0;
     return RADAD_OK;
 }
 

@@ -164,11 +164,12 @@ class MelProjectionFeatureExtractor:
             raise ValueError(f"clip_offsets of {what} were invalid ({', '.join(why)}); its embeddings are not those of the intended clips")
 
     def last_logmel_kind(self) -> str:
-        """"per_segment" (k_logmel_h: one transform per segment and frame) or "clip_frames" (k_logmel_h_clip: the frames overlapping
-        segments share are transformed once) -- which log-mel kernel the most recent call took"""
+        """"per_segment" (k_logmel_h: one transform per segment and frame), "clip_frames" (k_logmel_h_clip: the frames overlapping
+        segments share are transformed once, DFT-as-GEMM on the matrix pipe) or "clip_frames_fft" (k_logmel_fft_clip: the same work
+        list as a radix FFT on the vector ALU, the default) -- which log-mel kernel the most recent call took"""
         k = C.c_int()
         _lib.check(self._lib.radad_embed_last_logmel_kind(self._h, C.byref(k)), "radad_embed_last_logmel_kind")
-        return "clip_frames" if k.value == 1 else "per_segment"
+        return {0: "per_segment", 1: "clip_frames", 2: "clip_frames_fft"}[k.value]
 
     def profile(self, enable: bool = True):
         _lib.check(self._lib.radad_embed_profile(self._h, 1 if enable else 0), "radad_embed_profile")

@@ -202,7 +202,7 @@ def test_fuzz_embed_shared_frames(gpu, seed):
         wave = torch.from_numpy(np.concatenate(clips)).to(gpu)
         emb = fe.embed_clips(wave, offs)
         what = dict(seed=seed, case=case, T=T, H=H, F=F, levels=levels, mode=mode, norm=norm, lens=lens)
-        assert fe.last_logmel_kind() == "clip_frames", what
+        assert fe.last_logmel_kind().startswith("clip_frames"), what
         emb_dev = fe.embed_clips(wave, torch.from_numpy(offs).to(gpu))
         ref = O.embed_clips(clips, L, hop, fe.proj_w, fe.proj_b, tuple(levels), mode, normalize=norm)
         err = float(np.abs(emb.cpu().numpy() - ref).max())
