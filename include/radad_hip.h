@@ -308,13 +308,15 @@ int radad_embed_clip_chunks(int n_segments, int frames_per_segment, int hop_fram
 int radad_embed_fft_clip_chunks(int n_segments, int frames_per_segment, int hop_frames, int32_t* out5);
 /* The per-lane constant tables of k_logmel_fft_clip for a mel filter bank [201, 80] (host arithmetic only, no device needed;
  * tests/test_fft_tables.py drives a numpy restatement of the kernel's data flow with them and compares it with numpy.fft.rfft and the
- * oracle's log-mel).  tab_out must hold `cap` >= 2064 floats: 25 groups (index k1, or the sample group m for the window) of
+ * oracle's log-mel).  tab_out must hold `cap` >= 2224 floats: 25 groups (index k1, or the sample group m for the window) of
  * [hann(16 m + 2 r), hann(16 m + 2 r + 1)] [cos, sin of W200^(r k1)] [cos, sin of W400^k, k = 25 k2 + k1] [fb[k][b] / 4,
- * fb[k][b + 1] / 4, 4 b as int32 bits, 0], each for the 8 lanes of an octet (lane p holds the residue class r = p < 4 ? p : 11 - p
- * of the packed frame and ends with the bin block k2 = bitrev3(p)), then per lane the constants of the three exchange stages
- * [g1, c1, s1, g2, c2, s2, g3, 0]: own <- (own + g partner)(c + i s).  info4 = { 1 if every bin of the bank feeds at most two
- * adjacent bands (what the sparse mel step needs; otherwise the matrix-pipe kernels run), floats written, first band of bin 200,
- * 1 if bin 200 carries weight }. */
+ * fb[k][b + 1] / 4, byte offset of band b's slot in a row of the mel tile (int32 bits), 1 if the next bin starts at band b + 1
+ * (int32 bits)], each for the 8 lanes of an octet (lane p holds the residue class r = p < 4 ? p : 11 - p of the packed frame and
+ * ends with the bin block k2 = bitrev3(p)); then per lane the constants of the three exchange stages [g1, c1, s1, g2, c2, s2, g3, 0]:
+ * own <- (own + g partner)(c + i s); then per band the byte offsets (int32) of the two row slots that add up to it.  info4 =
+ * { 1 if the bank has the shape the sparse mel step needs (every bin feeds at most two adjacent bands, the band index never falls and
+ * rises by at most one per bin, bin 200 weightless; otherwise the matrix-pipe kernels run), floats written, floats per row of the mel
+ * tile, float offset of the band table }. */
 int radad_embed_fft_tables(const float* mel_filters_host, float* tab_out, int cap, int32_t* info4);
 
 /* same HIP-event timing for the two embedding kernels (k_logmel, k_proj_pool) of radad_embed_forward */

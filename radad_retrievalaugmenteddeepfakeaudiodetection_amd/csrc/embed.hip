@@ -105,8 +105,7 @@ struct LogmelParams {
     float fb1[2];                // filter-bank weights of bin 1 in mel bands 0 and 1
     // k_logmel_fft_clip (the same work list on the vector ALU: logmel_fft.inc)
     const float* fft_tab;        // [FC_TAB_FLOATS] lane tables (fc_build_tables)
-    float fb200[2];              // filter-bank weights of bin 200 in bands band200, band200 + 1 (zero in the Slaney bank)
-    int band200;
+    int fft_adv2;                // bit k1: some lane's band index rises by two after its bin k1
     int debug;                   // timing experiments only (RADAD_DEBUG_LOGMEL): 1 = skip the MFMA loop, 2 = skip the prologue
 };
 
@@ -681,21 +680,50 @@ struct DevBuf {
 
 // Lane tables of k_logmel_fft_clip (layout: logmel_fft.inc; data flow checked in numpy by tools/fft_design.py and, driven by THESE
 // tables, by tests/test_fft_tables.py).  Lane pl of an octet holds the residue class rr = pl < 4 ? pl : 11 - pl of the packed
-// frame and ends with the bin block k2 = bitrev3(pl).  Returns false when a bin of the filter bank feeds bands that are not two
-// adjacent ones (the sparse mel step cannot express that: the matrix-pipe kernels stay).
-static bool fc_build_tables(const float* fb /* [201][80] */, float* tab /* [FC_TAB_FLOATS] */, float fb200[2], int* band200) {
+// frame and ends with the bin block k2 = bitrev3(pl).  Returns false when the filter bank does not have the shape the sparse mel
+// step needs (then the matrix-pipe kernels stay): every bin feeds at most two ADJACENT bands (b, b + 1), b never falls and rises
+// by at most two from bin to bin (the Slaney bank's linear part has bands 37.2 Hz apart under bins 40 Hz apart: now and then b
+// skips one), no band is fed by more than two lanes, bin 200 carries no weight, the band slots fit a row.  *adv2_mask: bit k1 is
+// set when some lane's band index rises by two after its bin k1 (the kernel then stores both running sums at that step).
+static bool fc_build_tables(const float* fb /* [201][80] */, float* tab /* [FC_TAB_FLOATS] */, int* adv2_mask) {
     const double PI = 3.14159265358979323846;
     for (int i = 0; i < FC_TAB_FLOATS; ++i) tab[i] = 0.f;
-    auto bands_of = [&](int bin, int* b_out, float* wl, float* wh) -> bool {
+    *adv2_mask = 0;
+    int bnd[200];                                                    // first band of every bin
+    for (int k = 0; k < 200; ++k) {
         int first = -1, last = -1;
         for (int b = 0; b < N_MELS; ++b)
-            if (fb[bin * N_MELS + b] != 0.f) { if (first < 0) first = b; last = b; }
-        int b = first < 0 ? 0 : first;
+            if (fb[k * N_MELS + b] != 0.f) { if (first < 0) first = b; last = b; }
         if (first >= 0 && last - first > 1) return false;
-        if (b > N_MELS - 2) b = N_MELS - 2;
-        *b_out = b; *wl = fb[bin * N_MELS + b]; *wh = fb[bin * N_MELS + b + 1];
-        return true;
-    };
+        const int lo_ok = last < 0 ? 0 : std::max(0, last - 1), hi_ok = first < 0 ? N_MELS - 2 : std::min(first, N_MELS - 2);
+        if (lo_ok > hi_ok) return false;
+        if (k == 0) bnd[k] = lo_ok;
+        else {
+            if (bnd[k - 1] > hi_ok || lo_ok > bnd[k - 1] + 2) return false;       // the band index fell, or jumped by three
+            bnd[k] = std::max(bnd[k - 1], lo_ok);
+        }
+    }
+    for (int b = 0; b < N_MELS; ++b)
+        if (fb[(N_BINS - 1) * N_MELS + b] != 0.f) return false;       // bin 200 (= Re Z[0] - Im Z[0]) is not computed
+    int slot_base[8], n_slots[8], total = 0;                         // per bin block k2: its band slots in a row of the mel tile
+    for (int k2 = 0; k2 < 8; ++k2) {
+        slot_base[k2] = total;
+        n_slots[k2] = bnd[25 * k2 + 24] - bnd[25 * k2] + 2;
+        total += n_slots[k2];
+    }
+    if (total > FC_ROW_X1) return false;
+    int* comb = reinterpret_cast<int*>(tab + FC_COMB);
+    for (int m = 0; m < N_MELS; ++m) {
+        int n = 0;
+        comb[2 * m] = comb[2 * m + 1] = 4 * FC_ROW_ZERO;
+        for (int k2 = 0; k2 < 8; ++k2) {
+            const int j = m - bnd[25 * k2];
+            if (j >= 0 && j < n_slots[k2]) {
+                if (n == 2) return false;
+                comb[2 * m + n++] = 4 * (slot_base[k2] + j);
+            }
+        }
+    }
     for (int pl = 0; pl < 8; ++pl) {
         const int rr = pl < 4 ? pl : 11 - pl;
         const int k2 = ((pl & 1) << 2) | (pl & 2) | ((pl >> 2) & 1);
@@ -711,12 +739,14 @@ static bool fc_build_tables(const float* fb /* [201][80] */, float* tab /* [FC_T
             const int k = 25 * k2 + k1;                                         // the bin this lane ends with at k1
             t[32 + 2 * pl] = (float)cos(2.0 * PI * k / 400.0);
             t[32 + 2 * pl + 1] = (float)sin(2.0 * PI * k / 400.0);
-            int b; float wl, wh;
-            if (!bands_of(k, &b, &wl, &wh)) return false;
-            t[48 + 4 * pl] = 0.25f * wl;                                        // the kernel forms 4 |X|^2
-            t[48 + 4 * pl + 1] = 0.25f * wh;
-            const int boff = 4 * b;
-            memcpy(&t[48 + 4 * pl + 2], &boff, sizeof(int));
+            const int b = bnd[k];
+            t[48 + 4 * pl] = 0.25f * fb[k * N_MELS + b];                        // the kernel forms 4 |X|^2
+            t[48 + 4 * pl + 1] = 0.25f * fb[k * N_MELS + b + 1];
+            const int soff = 4 * (slot_base[k2] + b - bnd[25 * k2]);            // byte offset of band b's slot in the row
+            const int adv = k1 == 24 ? 1 : bnd[k + 1] - b;                      // how far the running sums shift after this bin (0, 1, 2)
+            if (adv == 2) *adv2_mask |= 1 << k1;
+            memcpy(&t[48 + 4 * pl + 2], &soff, sizeof(int));
+            memcpy(&t[48 + 4 * pl + 3], &adv, sizeof(int));
         }
         // exchange stages: own <- (own + g partner)(c + i s).  Stage t pairs index i with i +- half inside the lane's branch; the lane
         // whose bit (2, 1, 0) of pl is clear keeps the sum, the other (x_small - x_big) W8^e.  A stage without multiply (the third) cannot
@@ -748,9 +778,6 @@ static bool fc_build_tables(const float* fb /* [201][80] */, float* tab /* [FC_T
             idx %= half;
         }
     }
-    int b; float wl, wh;
-    if (!bands_of(N_BINS - 1, &b, &wl, &wh)) return false;
-    fb200[0] = wl; fb200[1] = wh; *band200 = b;
     return true;
 }
 
@@ -775,8 +802,7 @@ struct radad_embed_s {
     // and a filter bank whose bins feed at most two adjacent bands (triangular filters); RADAD_EMBED_DFT_GEMM keeps k_logmel_h_clip
     int logmel_fft = 0;
     float* fft_tab = nullptr;
-    float fb200[2] = {0.f, 0.f};
-    int band200 = 0;
+    int fft_adv2 = 0;                    // steps at which some lane's mel band index rises by two (fc_build_tables)
     int64_t plan_nchunks = 0;            // interior chunks of the cached plan (host-sized plans), or their upper bound (device-sized)
     bool plan_has_chunks = false;        // the cached plan carries the chunk arrays
     DevBuf seg_stats, chunk_rec;
@@ -919,7 +945,7 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
     p.seg_max = (float*)h->seg_max.p; p.norm_out = norm_out; p.n_seg_dev = n_seg_dev;
     p.seg_stats = nullptr; p.clip_seg = nullptr; p.chunk_rec = nullptr; p.prefetch_dist = 0;
     p.seg_hop = 0; p.seg_hop_frames = 0; p.chunk_cap = 0; p.n_chunks = 0; p.fb1[0] = p.fb1[1] = 0.f;
-    p.fft_tab = nullptr; p.fb200[0] = p.fb200[1] = 0.f; p.band200 = 0;
+    p.fft_tab = nullptr; p.fft_adv2 = 0;
     p.debug = 0;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (tools/exp_logmel.sh builds with -DRADAD_DEBUG_HOOKS); never in the shipped library
     { const char* dbg = getenv("RADAD_DEBUG_LOGMEL"); p.debug = dbg ? atoi(dbg) : 0; }
@@ -946,7 +972,7 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
         p.n_chunks = (int)h->plan_nchunks;
         p.fb1[0] = h->fb1[0]; p.fb1[1] = h->fb1[1];
         p.plane_halfs = LH_CLIP_PLANE_HALFS;
-        p.fft_tab = h->fft_tab; p.fb200[0] = h->fb200[0]; p.fb200[1] = h->fb200[1]; p.band200 = h->band200;
+        p.fft_tab = h->fft_tab; p.fft_adv2 = h->fft_adv2;
         if (h->logmel_fft)
             hipLaunchKernelGGL(k_logmel_fft_clip, dim3((unsigned)h->plan_nchunks), dim3(FC_THREADS), logmel_fft_lds_bytes(), st, p);
         else
@@ -1136,7 +1162,7 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
     std::vector<float> fft_tab(FC_TAB_FLOATS);
     {
         // the shared-frame work list as a radix FFT on the vector ALU whenever the configuration allows sharing and the filter bank is triangular
-        bool ok = h->share_frames && !h->logmel_f32 && fc_build_tables(mel_filters_host, fft_tab.data(), h->fb200, &h->band200);
+        bool ok = h->share_frames && !h->logmel_f32 && fc_build_tables(mel_filters_host, fft_tab.data(), &h->fft_adv2);
         const char* e = radad_env_override("RADAD_LOGMEL_FFT", "0 keeps the DFT-as-GEMM log-mel kernel (k_logmel_h_clip) instead of the radix FFT (k_logmel_fft_clip) for extractors created from now on");
         if (e && atoi(e) == 0) ok = false;
         h->logmel_fft = ok ? 1 : 0;
@@ -1326,10 +1352,9 @@ int radad_embed_fft_clip_chunks(int n_segments, int frames_per_segment, int hop_
 
 int radad_embed_fft_tables(const float* mel_filters_host, float* tab_out, int cap, int32_t* info4) {
     RADAD_REQUIRE(mel_filters_host && tab_out && info4 && cap >= FC_TAB_FLOATS, "radad_embed_fft_tables: bad argument (the table holds %d floats)", FC_TAB_FLOATS);
-    float fb200[2] = {0.f, 0.f};
-    int band200 = 0;
-    const bool ok = fc_build_tables(mel_filters_host, tab_out, fb200, &band200);
-    info4[0] = ok ? 1 : 0; info4[1] = FC_TAB_FLOATS; info4[2] = band200; info4[3] = (fb200[0] != 0.f || fb200[1] != 0.f) ? 1 : 0;
+    int adv2 = 0;
+    const bool ok = fc_build_tables(mel_filters_host, tab_out, &adv2);
+    info4[0] = ok ? 1 : 0; info4[1] = FC_TAB_FLOATS; info4[2] = adv2; info4[3] = FC_COMB;
     return RADAD_OK;
 }
 
