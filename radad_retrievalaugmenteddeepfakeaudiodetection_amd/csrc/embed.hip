@@ -974,7 +974,8 @@ static int launch_logmel(radad_embed_t h, const float* wave_dev, int64_t n_seg, 
         p.plane_halfs = LH_CLIP_PLANE_HALFS;
         p.fft_tab = h->fft_tab; p.fft_adv2 = h->fft_adv2;
         if (h->logmel_fft)
-            hipLaunchKernelGGL(k_logmel_fft_clip, dim3((unsigned)h->plan_nchunks), dim3(FC_THREADS), logmel_fft_lds_bytes(), st, p);
+            hipLaunchKernelGGL(k_logmel_fft_clip, dim3((unsigned)std::min<int64_t>(h->plan_nchunks, 2 * (int64_t)h->n_cus)), dim3(FC_THREADS),
+                               logmel_fft_lds_bytes(), st, p);       // persistent: two workgroups per CU walk the chunk list
         else
             hipLaunchKernelGGL(k_logmel_h_clip, dim3((unsigned)h->plan_nchunks), dim3(LH_THREADS), logmel_h_clip_lds_bytes(), st, p);
     } else if (h->logmel_f32) hipLaunchKernelGGL(k_logmel, dim3((unsigned)n_seg), dim3(LM_THREADS), logmel_lds_bytes(), st, p);

@@ -1,0 +1,11 @@
+#!/bin/bash
+# the two SQ counter passes of tools/pmc_cmd.sh only (no FETCH_SIZE pass): tools/pmc_sq.sh <tag> <script.py> [args...]   (run through gpurun)
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+TAG=$1; shift
+OUT=gpurun_out/pmc_$TAG
+echo "pass sq1"
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA --output-format csv -d $OUT/sq1 -o p -- python3 "$@" > $OUT.sq1.log 2>&1 || exit 1
+echo "pass sq2"
+rocprofv3 --kernel-trace --pmc SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM --output-format csv -d $OUT/sq2 -o p -- python3 "$@" > $OUT.sq2.log 2>&1 || exit 1
+python3 tools/pmc_summary.py $OUT/sq1 $OUT/sq2 > $OUT.summary.txt 2>&1
