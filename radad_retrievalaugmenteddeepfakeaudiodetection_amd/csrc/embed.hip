@@ -491,6 +491,293 @@ __global__ __launch_bounds__(PP_WAVES * 64, PP_WAVES / 4) void k_proj_pool(ProjP
     }
 }
 
+// ---- projection + pooling, software-pipelined (the path of radad_embed_forward) ---------------------------------------------------
+// k_proj_pool above runs `stage a segment's log-mel rows (global loads -> clamp, scale, split -> LDS)` and `multiply, pool` back to
+// back behind barriers: 0.21 ms for 0.077 ms of matrix work.  Not the loads' latency (a first pipelined form that only prefetched
+// the rows into registers measured the same 0.21): the VECTOR work.  A gfx950 SIMD issues a wave64 vector instruction in 4 cycles,
+// and the kernel spent 11 of them per MFMA -- converting 36 values per thread and pass (9 instructions each) with the matrix pipe
+// idle behind a barrier, then scaling, biasing and pooling every accumulator element in both pooling modes at once (4 per element).
+// Here: 8 waves x 64 features walk the (clip, segment, 128-frame pass) list of a persistent workgroup through TWO LDS plane
+// buffers.  While the MFMAs of pass k run from one buffer, the rows of pass k + 1 (loaded a pass earlier) are converted into the
+// other, a slice per tile -- vector instructions that issue between the MFMAs of the same wave -- and the rows of pass k + 2 are
+// requested as soon as that conversion has freed their registers.  The conversion is 4.5 instructions per value (one fma for (x + 4) / 4 . 2^12, packed f16 conversions); max pooling is
+// one v_max3_f32 per two accumulator elements, scale and bias applied to the pooled value (a monotone map commutes with max, bit
+// for bit); the pooling mode is a template parameter.
+constexpr int PP2_WAVES = 8;
+constexpr int PP2_THREADS = PP2_WAVES * 64;
+constexpr int PP2_PB = 128;                                  // frames per pass: 4 tiles
+constexpr int PP2_RAW = PP2_PB * (N_MELS / 4) / PP2_THREADS; // 128-bit row pieces per thread and pass: 5
+static_assert(PP2_RAW * PP2_THREADS == PP2_PB * (N_MELS / 4), "a pass is a whole number of 128-bit pieces per thread");
+constexpr size_t projpool2_lds_bytes(int nt) {
+    return sizeof(_Float16) * 2 * 2 * PP2_PB * PP_LDH + sizeof(float) * 2 * MAX_BINS_TOTAL * PP2_WAVES * 32 * nt;
+}
+__device__ __forceinline__ int64_t pp2_scalar_i64(const int64_t* ptr) {          // through the scalar cache (written by k_build_plan only)
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(4))) int64_t* ci_p;
+    return *((ci_p)(uintptr_t)ptr);
+#else
+    return *ptr;
+#endif
+}
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+struct PP2Item { int clip, s, s_first, s_end, f0, valid; };      // (plain ints, copied field by field: hipcc otherwise keeps the items in scratch)
+
+template <int NT, int MODE>
+__global__ __launch_bounds__(PP2_THREADS, 2) void k_proj_pool2(ProjPoolParams p, int n_groups_host) {
+    constexpr int FEATS = PP2_WAVES * 32 * NT;
+    constexpr int PLANE = PP2_PB * PP_LDH;                   // halfs per plane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    _Float16* planes = reinterpret_cast<_Float16*>(smem);    // [2 buffers][hi, lo][PP2_PB][PP_LDH]
+    float* spool = reinterpret_cast<float*>(planes + 4 * PLANE);       // [nbins][FEATS]  current segment
+    float* sclip = spool + MAX_BINS_TOTAL * FEATS;           // [nbins][FEATS]  running sum over the clip's segments
+    __shared__ int s_lo[MAX_BINS_TOTAL], s_hi[MAX_BINS_TOTAL];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int lh = lane >> 5;
+    const int fblk = blockIdx.y;
+    const int n_groups = p.n_groups_dev ? min(*p.n_groups_dev, n_groups_host) : n_groups_host;
+    if ((int)blockIdx.x >= n_groups) return;                 // (uniform per workgroup)
+
+    int nbins = 0;
+    for (int l = 0; l < p.n_levels; ++l) nbins += p.levels[l];
+    if (tid < nbins) {                                       // frame range [lo, hi) of every pooling bin (pooling.py:78-83)
+        int b0 = 0, l = 0;
+        while (tid >= b0 + p.levels[l]) { b0 += p.levels[l]; ++l; }
+        const int lv = p.levels[l], i = tid - b0;
+        s_lo[tid] = (int)(((int64_t)i * p.T) / lv);
+        s_hi[tid] = (int)(((int64_t)(i + 1) * p.T + lv - 1) / lv);
+    }
+    // W fragments of the wave's NT feature tiles: lane holds W[16 st + 8 lh + j][feat] (hi and lo), st = 0..4 (K = 80)
+    bool active[NT];
+    int feat[NT], fl[NT];
+    f16x8 wh[NT][5], wl[NT][5];
+    float wsc[NT], bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int ftile = (fblk * PP2_WAVES + wave) * NT + nt;
+        active[nt] = ftile * 32 < p.F;                       // tiles past F only keep the barriers company
+        const int ft = active[nt] ? ftile : 0;
+        feat[nt] = ft * 32 + l31;
+        fl[nt] = (wave * NT + nt) * 32 + l31;                // feature column inside the block
+#pragma unroll
+        for (int st = 0; st < 5; ++st) {
+            wh[nt][st] = *reinterpret_cast<const f16x8*>(p.wfrag_h + ((((int64_t)ft * 5 + st) * 2 + 0) * 64 + lane) * 8);
+            wl[nt][st] = *reinterpret_cast<const f16x8*>(p.wfrag_h + ((((int64_t)ft * 5 + st) * 2 + 1) * 64 + lane) * 8);
+        }
+        wsc[nt] = p.wscale[feat[nt]];
+        bias[nt] = p.bias[feat[nt]];
+    }
+
+    // the walk: (group, segment, pass); a group is a clip, or one segment when clip_seg is null (ragged batches)
+    auto first_of = [&](int c, PP2Item& it) {
+        it.clip = c; it.f0 = 0; it.valid = c < n_groups ? 1 : 0;
+        it.s = it.s_first = it.s_end = 0;
+        if (it.valid) {
+            if (p.clip_seg) { it.s = (int)pp2_scalar_i64(p.clip_seg + c); it.s_end = (int)pp2_scalar_i64(p.clip_seg + c + 1); }
+            else { it.s = c; it.s_end = c + 1; }
+            it.s_first = it.s;
+        }
+    };
+    auto next_of = [&](const PP2Item& cur, PP2Item& nx) {
+        const int clip = cur.clip, sg = cur.s, sf = cur.s_first, se = cur.s_end, f0 = cur.f0, v = cur.valid;
+        if (v && f0 + PP2_PB < p.T) { nx.clip = clip; nx.s = sg; nx.s_first = sf; nx.s_end = se; nx.f0 = f0 + PP2_PB; nx.valid = 1; }
+        else if (v && sg + 1 < se) { nx.clip = clip; nx.s = sg + 1; nx.s_first = sf; nx.s_end = se; nx.f0 = 0; nx.valid = 1; }
+        else if (v) first_of(clip + (int)gridDim.x, nx);
+        else { nx.clip = clip; nx.s = sg; nx.s_first = sf; nx.s_end = se; nx.f0 = f0; nx.valid = 0; }
+    };
+    // rows f0 .. f0 + 127 of the item's segment into registers, clamped into the stored frames (what lies beyond is decided when
+    // converting); the segment's maximum with them
+    auto issue = [&](const PP2Item& it, f32x4 (&raw)[PP2_RAW], float& smax) {
+        if (!it.valid) return;
+        const float* base = p.logmel + (int64_t)it.s * p.nf * N_MELS;
+#pragma unroll
+        for (int u = 0; u < PP2_RAW; ++u) {
+            const int i = u * PP2_THREADS + tid;
+            const int fr = i / (N_MELS / 4), c4 = i % (N_MELS / 4);
+            const int tt = min(it.f0 + fr, p.nf - 1);
+            raw[u] = *reinterpret_cast<const f32x4*>(base + (int64_t)tt * N_MELS + c4 * 4);
+        }
+        smax = p.seg_max[it.s];
+    };
+    // one 128-bit piece of a pass: clamp to max - 8, (x + 4) / 4 (feature_extraction_whisper.py:161-162) scaled by 2^12 -- one fma,
+    // rounded once like (x + 4) / 4 . 2^12 --, split into the two f16 planes of buffer `buf`
+    auto convert = [&](const PP2Item& it, const f32x4 (&raw)[PP2_RAW], float smax, int u, int buf) {
+        const int i = u * PP2_THREADS + tid;
+        const int fr = i / (N_MELS / 4), c4 = i % (N_MELS / 4);
+        const int tt = it.f0 + fr;
+        f32x4 v = raw[u];
+        if (!(tt < p.T && tt < p.nf)) v = f32x4{-10.f, -10.f, -10.f, -10.f};      // log10(1e-10): a frame of pure zero padding
+        const float floor_v = smax - 8.0f;
+        f16x4 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+            const float s0 = fmaf(fmaxf(v[e], floor_v), 1024.f, 4096.f), s1 = fmaf(fmaxf(v[e + 1], floor_v), 1024.f, 4096.f);
+            const f16x2 h2 = f16x2{(_Float16)s0, (_Float16)s1};
+            const f16x2 l2 = f16x2{(_Float16)(s0 - (float)h2[0]), (_Float16)(s1 - (float)h2[1])};
+            vh[e] = h2[0]; vh[e + 1] = h2[1];
+            vl[e] = l2[0]; vl[e + 1] = l2[1];
+        }
+        _Float16* ph = planes + (size_t)buf * 2 * PLANE;
+        *reinterpret_cast<f16x4*>(ph + fr * PP_LDH + c4 * 4) = vh;
+        *reinterpret_cast<f16x4*>(ph + PLANE + fr * PP_LDH + c4 * 4) = vl;
+    };
+
+    // the pieces converted beside tile `tile` (wave-uniform; static register indices: a run-time index would put the rows in scratch)
+    auto convert_slice = [&](const PP2Item& it, const f32x4 (&raw)[PP2_RAW], float smax, int tile, int buf) {
+        switch (tile) {
+            case 0: convert(it, raw, smax, 0, buf); break;
+            case 1: convert(it, raw, smax, 1, buf); break;
+            case 2: convert(it, raw, smax, 2, buf); break;
+            default: convert(it, raw, smax, 3, buf); convert(it, raw, smax, 4, buf); break;
+        }
+    };
+    // one pass: MFMAs of `cur` from buffer `buf`, the conversion of `nxt` (rows in rawc) into the other buffer a slice per tile
+    auto pass = [&](const PP2Item& cur, int buf, const PP2Item& nxt, const f32x4 (&rawc)[PP2_RAW], float smaxc) {
+        const _Float16* slm_h = planes + (size_t)buf * 2 * PLANE;
+        const _Float16* slm_l = slm_h + PLANE;
+        if (cur.f0 == 0 && lh == 0) {                        // (columns are wave-private: no barrier for these)
+            const float init = MODE == RADAD_POOL_MAX ? -INFINITY : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                for (int b = 0; b < nbins; ++b) spool[b * FEATS + fl[nt]] = init;
+                if (cur.s == cur.s_first)
+                    for (int b = 0; b < nbins; ++b) sclip[b * FEATS + fl[nt]] = 0.f;
+            }
+        }
+        const int fcount = min(PP2_PB, p.T - cur.f0);
+        const int ntile = (fcount + 31) / 32;
+        // pooling of one accumulator tile: acc[r] = feature feat[nt] of frame tfirst + (r&3) + 8(r>>2) + 4lh, before the scale and the bias
+        auto pool_tile = [&](int nt, const f32x16& acc, int tfirst, int tlast) {
+            if (!active[nt]) return;
+            for (int b = 0; b < nbins; ++b) {
+                const int lo = s_lo[b], hi = s_hi[b];
+                if (hi <= tfirst || lo >= tlast) continue;        // wave-uniform
+                float v = MODE == RADAD_POOL_MAX ? -INFINITY : 0.f;
+                if (lo <= tfirst && tfirst + 32 <= hi) {          // whole tile inside the bin (wave-uniform)
+                    if (MODE == RADAD_POOL_MAX) {
+                        // v_max3_f32 by hand: fmaxf() quiets NaNs first (one v_max x, x per operand: 28 instructions instead of 8)
+#pragma unroll
+                        for (int r = 0; r < 16; r += 2) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(v) : "v"(acc[r]), "v"(acc[r + 1]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v += fmaf(acc[r], wsc[nt], bias[nt]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int tt = tfirst + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const bool in = tt >= lo && tt < hi;      // hi <= T
+                        if (MODE == RADAD_POOL_MAX) v = in ? fmaxf(v, acc[r]) : v;
+                        else v += in ? fmaf(acc[r], wsc[nt], bias[nt]) : 0.f;
+                    }
+                }
+                const float o = __shfl_xor(v, 32, 64);
+                if (lh == 0) {
+                    float* dst = spool + b * FEATS + fl[nt];
+                    // max: the exact power-of-two un-scale and the bias are monotone, so they commute with the maximum bit for bit
+                    if (MODE == RADAD_POOL_MAX) *dst = fmaxf(*dst, fmaf(fmaxf(v, o), wsc[nt], bias[nt]));
+                    else *dst += v + o;
+                }
+            }
+        };
+#pragma unroll 1
+        for (int tile = 0; tile < 4; ++tile) {
+            if (tile < ntile) {
+                const int aoff = (tile * 32 + l31) * PP_LDH + 8 * lh;
+                const int tfirst = cur.f0 + tile * 32;
+                const int tlast = min(tfirst + 32, p.T);     // exclusive
+                // A wave issues in order: vector work placed BEHIND a block of MFMAs only starts when the last of them has been issued,
+                // i.e. when the pipe is nearly drained.  So the tile's vector work sits INSIDE the MFMA chains: the conversion of the next
+                // pass's rows behind the first k-step of the first feature tile, the pooling of the first feature tile behind the
+                // second k-step of the second one (its accumulators are complete by then); only the last pooling is exposed.
+                f32x16 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+                    for (int st = 0; st < 5; ++st) {
+                        const f16x8 ah = *reinterpret_cast<const f16x8*>(slm_h + aoff + st * 16);
+                        const f16x8 al = *reinterpret_cast<const f16x8*>(slm_l + aoff + st * 16);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[nt][st], acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[nt][st], acc[nt], 0, 0, 0);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[nt][st], acc[nt], 0, 0, 0);
+                        // (fences only around the inserted blocks: elsewhere hipcc keeps the fragment reads two k-steps ahead of their MFMAs)
+                        if (nt == 0 && st == 0 && nxt.valid) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            convert_slice(nxt, rawc, smaxc, tile, buf ^ 1);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (nt == 1 && st == 1) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            pool_tile(0, acc[0], tfirst, tlast);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                pool_tile(NT - 1, acc[NT - 1], tfirst, tlast);
+            } else if (nxt.valid) convert_slice(nxt, rawc, smaxc, tile, buf ^ 1);      // a short pass: the slices its missing tiles would have converted
+        }
+        // segment done: its vector into the clip's running sum; clip done: the mean leaves (pipeline.py:411)
+        if (cur.f0 + PP2_PB >= p.T && lh == 0) {
+            const bool last_seg = cur.s + 1 >= cur.s_end;
+            const float nseg = (float)(cur.s_end - cur.s_first);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (!active[nt]) continue;
+                for (int b = 0; b < nbins; ++b) {
+                    float v = spool[b * FEATS + fl[nt]];
+                    if (MODE == RADAD_POOL_AVG) v = v / (float)(s_hi[b] - s_lo[b]);
+                    v += sclip[b * FEATS + fl[nt]];
+                    if (!last_seg) sclip[b * FEATS + fl[nt]] = v;
+                    else {
+                        v = v / nseg;
+                        const int64_t o = (int64_t)cur.clip * nbins * p.F + (int64_t)b * p.F + feat[nt];
+                        if (p.out_bf16) p.out_bf16[o] = f32_to_bf16_rne(v);
+                        else p.out[o] = v;
+                    }
+                }
+            }
+        }
+    };
+
+    // Three passes in the pipe: it0 multiplies from buffer 0 / 1, it1 (its rows loaded a whole pass ago) is converted into the other
+    // buffer, it2 loads.  Two register sets take turns (static indices: the loop body is written out for both roles).  A single set
+    // -- request the rows as soon as the conversion has freed the registers -- was measured first: every pass then started by
+    // waiting ~1.5 us for rows requested ~0.1 us earlier (46 % of the wave cycles in s_waitcnt: 0.19 ms, no faster than k_proj_pool).
+    PP2Item it0, it1, it2;
+    first_of((int)blockIdx.x, it0);
+    next_of(it0, it1);
+    next_of(it1, it2);
+    f32x4 rawA[PP2_RAW], rawB[PP2_RAW];
+    float smaxA = 0.f, smaxB = 0.f;
+    issue(it0, rawA, smaxA);
+    issue(it1, rawB, smaxB);
+#pragma unroll
+    for (int u = 0; u < PP2_RAW; ++u) convert(it0, rawA, smaxA, u, 0);
+    issue(it2, rawA, smaxA);                                 // (rawA is free again)
+    __syncthreads();
+    auto copy_item = [](PP2Item& d, const PP2Item& x) { d.clip = x.clip; d.s = x.s; d.s_first = x.s_first; d.s_end = x.s_end; d.f0 = x.f0; d.valid = x.valid; };
+    while (it0.valid) {
+        pass(it0, 0, it1, rawB, smaxB);                      // it1: rawB -> buffer 1; it2 is loading into rawA
+        PP2Item it3;
+        next_of(it2, it3);
+        issue(it3, rawB, smaxB);                             // (rawB is free again)
+        __syncthreads();
+        if (!it1.valid) break;
+        pass(it1, 1, it2, rawA, smaxA);                      // it2: rawA -> buffer 0; it3 is loading into rawB
+        PP2Item it4;
+        next_of(it3, it4);
+        issue(it4, rawA, smaxA);
+        __syncthreads();
+        copy_item(it0, it2); copy_item(it1, it3); copy_item(it2, it4);
+    }
+}
+
 // finalise log-mel for the stage API: out[s][t][m] = (max(x, smax-8)+4)/4, frames >= nf are silence
 __global__ void k_logmel_finalize(const float* __restrict__ logmel, const float* __restrict__ seg_max, int nf, int T,
                                   int64_t n_seg, float* __restrict__ out) {
@@ -1185,6 +1472,14 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
                                 (int)logmel_h_clip_lds_bytes()) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_logmel_fft_clip), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)logmel_fft_lds_bytes()) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool2<1, RADAD_POOL_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)projpool2_lds_bytes(1)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool2<1, RADAD_POOL_AVG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)projpool2_lds_bytes(1)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool2<2, RADAD_POOL_MAX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)projpool2_lds_bytes(2)) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool2<2, RADAD_POOL_AVG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)projpool2_lds_bytes(2)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)projpool_lds_bytes(8)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_proj_pool<false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1253,11 +1548,17 @@ static int embed_run(radad_embed_t h, const float* wave_dev, int64_t n_clips, in
         n_groups = n_seg_grid;
     }
     h->prof_pool.begin(st);
-    if (h->cfg.feat_dim > 256)
-        hipLaunchKernelGGL((k_proj_pool<false, 16>), dim3((unsigned)n_groups, (unsigned)((h->cfg.feat_dim + 511) / 512)), dim3(1024),
-                           projpool_lds_bytes(16), st, p);
-    else
-        hipLaunchKernelGGL((k_proj_pool<false, 8>), dim3((unsigned)n_groups, 1), dim3(512), projpool_lds_bytes(8), st, p);
+    // persistent workgroups (one per CU) walk the groups; the next pass's rows are in flight across the current pass's MFMAs
+    const unsigned gx = (unsigned)std::min<int64_t>(n_groups, h->n_cus);
+    const bool pmax = h->cfg.pool_mode == RADAD_POOL_MAX;
+    if (h->cfg.feat_dim > 256) {
+        const dim3 grid(gx, (unsigned)((h->cfg.feat_dim + 511) / 512));
+        if (pmax) hipLaunchKernelGGL((k_proj_pool2<2, RADAD_POOL_MAX>), grid, dim3(PP2_THREADS), projpool2_lds_bytes(2), st, p, (int)n_groups);
+        else hipLaunchKernelGGL((k_proj_pool2<2, RADAD_POOL_AVG>), grid, dim3(PP2_THREADS), projpool2_lds_bytes(2), st, p, (int)n_groups);
+    } else {
+        if (pmax) hipLaunchKernelGGL((k_proj_pool2<1, RADAD_POOL_MAX>), dim3(gx, 1), dim3(PP2_THREADS), projpool2_lds_bytes(1), st, p, (int)n_groups);
+        else hipLaunchKernelGGL((k_proj_pool2<1, RADAD_POOL_AVG>), dim3(gx, 1), dim3(PP2_THREADS), projpool2_lds_bytes(1), st, p, (int)n_groups);
+    }
     if (!per_clip)                        // pipeline.py:411: mean over each clip's segment vectors, in segment order
         hipLaunchKernelGGL(k_group_mean, dim3((unsigned)n_clips, (unsigned)((out_dim + 255) / 256)), dim3(256), 0, st,
                            (const float*)h->seg_pool.p, (const int64_t*)h->clip_seg.p, out_dim, bf16 ? nullptr : (float*)out_dev,

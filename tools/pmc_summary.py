@@ -7,7 +7,7 @@ import os
 import sys
 from collections import defaultdict
 
-KEEP = ("k_knn_hi_sample", "k_knn_hi_smallq", "k_knn_hi", "k_knn_f32", "k_exact_scan", "k_exact_merge", "k_hi_rows", "k_build_plan", "k_seg_stats", "k_logmel_fft_clip", "k_logmel_h_clip", "k_logmel", "k_proj_pool", "k_merge_refine", "k_rows_prepare", "k_split_rows", "k_thr_from_parts", "k_floor_from_sample", "k_kth_floor")
+KEEP = ("k_knn_hi_sample", "k_knn_hi_smallq", "k_knn_hi", "k_knn_f32", "k_exact_scan", "k_exact_merge", "k_hi_rows", "k_build_plan", "k_seg_stats", "k_logmel_fft_clip", "k_proj_pool2", "k_logmel_h_clip", "k_logmel", "k_proj_pool", "k_merge_refine", "k_rows_prepare", "k_split_rows", "k_thr_from_parts", "k_floor_from_sample", "k_kth_floor")
 for d in sys.argv[1:]:
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         acc = defaultdict(lambda: defaultdict(list))
