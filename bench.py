@@ -41,6 +41,7 @@ AUDIO_SEED, DB_SEED, NOISE_SEED = 1234, 4321, 99
 PEAK_MFMA_F32_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: fp32-input MFMA, dense
 PEAK_MFMA_F16_TFLOPS = 2500.0     # same guide: BF16/F16 MFMA ~2.5 PF dense (at 2.4 GHz; MFMA-dense loops hold 1.5-1.95 GHz)
 PEAK_HBM_GBPS = 8000.0
+PEAK_VALU_F32_TFLOPS = 157.3      # same guide: fp32 vector peak (reached with packed fp32: 256 CUs x 4 SIMDs x 16 lanes x 2 x 2 x 2.4 GHz)
 
 
 def scan_traffic_from_profiles(section):
@@ -51,8 +52,11 @@ def scan_traffic_from_profiles(section):
     number in `traffic_source`.  Infinity-Cache hits are counted in FETCH_SIZE: an upper bound on DRAM traffic."""
     import glob
     import re
+    def round_key(path):        # r3_d_pmc_summary.txt -> (3, "d"): by round NUMBER, then letter (a plain sort puts r10 before r3)
+        m = re.match(r"r(\d+)_([a-z0-9]*)_", os.path.basename(path))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
     cand = [os.environ["RADAD_PMC_SUMMARY"]] if os.environ.get("RADAD_PMC_SUMMARY") else \
-        sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")))
+        sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.txt")), key=round_key)
     for path in reversed(cand):
         try:
             text = open(path).read()
@@ -88,8 +92,14 @@ def main():
                     "(pinned host -> device, double-buffered on a copy stream, overlapped with the previous step); 0 = skip")
     ap.add_argument("--unstructured", type=int, default=10, help="searches of 1024 random (unstructured) queries timed after the "
                     "headline steps for the `scan_unstructured_ms` key (0 = skip)")
-    ap.add_argument("--shard-bound", type=int, default=1, help="N > 1: 1 = exchange per-query k-th-best bounds between scan and "
-                    "re-rank (default), 0 = every shard certifies its own top k")
+    ap.add_argument("--shard-bound", type=int, default=0, help="N > 1, --parallelism shard: 1 = exchange per-query k-th-best bounds between "
+                    "scan and re-rank (pays on stores whose queries have distinct neighbourhoods; on this benchmark's data, where every "
+                    "planted row neighbours every query, it costs 2.5-8.8 %%: profiles/r3_e_rehearse.txt), 0 (default) = every shard "
+                    "certifies its own top k")
+    ap.add_argument("--parallelism", choices=["shard", "replicate"], default="shard",
+                    help="N > 1: shard (default, north_star) = the store is row-sharded, every rank scans all queries against its "
+                         "shard, the per-shard lists are exchanged and merged; replicate = every rank holds the WHOLE store and searches "
+                         "only its own clips: no collective at all (any BASELINE store fits one 288 GB GPU)")
     ap.add_argument("--mode", choices=["step", "predict"], default="step")
     ap.add_argument("--predict-queries", type=int, default=1)
     ap.add_argument("--dim", type=int, default=DIM, help="--mode predict only: embedding dimension of the store (the reference's own "
@@ -134,7 +144,7 @@ def main():
 
     import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
     from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
-    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import ShardedSearch, shard_bounds
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import ReplicatedSearch, ShardedSearch, shard_bounds
     lib = _lib.load()
 
     if args.mode == "predict" and (args.dim != DIM or args.metric != "cosine" or args.k != TOP_K):
@@ -184,7 +194,8 @@ def main():
     B = args.clips
     n_total = args.db_rows
     f16_store = args.store_dtype == "f16"
-    lo, hi = shard_bounds(n_total, world, rank)
+    replicate = world > 1 and args.parallelism == "replicate"
+    lo, hi = (0, n_total) if replicate else shard_bounds(n_total, world, rank)
     emb_dtype = torch.bfloat16 if args.embed_dtype == "bf16" else torch.float32
 
     # ---- inputs, resident in HBM before the timed region -------------------------------------------------
@@ -225,7 +236,7 @@ def main():
     rows = torch.empty((hi - lo, DIM), device=dev, dtype=torch.float32)
     _lib.check(lib.radad_synth_rows(rows.data_ptr(), lo, hi - lo, DIM, DB_SEED, local_rank, _lib.stream_ptr(dev)))
     # plant two near-duplicates of every query (of batch 0) so that the top of each list is known and non-trivial
-    Q = world * B
+    Q = world * B                                                     # (queries a rank SCANS: all of them when sharded)
     noise = torch.empty((2 * Q, DIM), device=dev)
     _lib.check(lib.radad_synth_rows(noise.data_ptr(), 0, 2 * Q, DIM, NOISE_SEED, local_rank, _lib.stream_ptr(dev)))
     jj = torch.arange(Q, device=dev)
@@ -235,7 +246,7 @@ def main():
         mine = (g >= lo) & (g < hi)
         rows[g[mine] - lo] = all_emb[mine] + eps * scale[mine] * noise[c * Q:(c + 1) * Q][mine]
     vdb = R.VectorDatabase(cfg)
-    vdb.create_index(DIM, id_base=lo)                                 # cosine: rows are normalised by the add kernel
+    vdb.create_index(DIM, id_base=lo)                                 # cosine: rows are normalised by the add kernel (replicate: lo = 0)
     vdb.index.reserve(hi - lo)
     vdb.index.add_device(rows)
     torch.cuda.synchronize()
@@ -249,12 +260,15 @@ def main():
     # N > 1: the search runs in two halves around an all-reduce(max) of per-query bounds (sharded.py), so that every shard
     # re-ranks only what can be among the GLOBAL top k
     bounded = None
-    if world > 1 and args.shard_bound:
+    if world > 1 and args.shard_bound and not replicate:
         def _finish(lb):
             _, ids, key64 = vdb.index.search_finish(lb, return_f64=True)
             return key64, ids
-        bounded = (vdb.index.search_begin, _finish)
-    searcher = ShardedSearch(local_search, vdb.index.metric, bounded=bounded, timing=world > 1)
+        bounded = (vdb.index.search_begin, _finish, vdb.index.search_abort)
+    if replicate:                                           # the whole store on every rank: a rank's search is the one-GPU search
+        searcher = ReplicatedSearch(lambda q, k: vdb.index.search_device(q, k))
+    else:
+        searcher = ShardedSearch(local_search, vdb.index.metric, bounded=bounded, timing=world > 1)
 
     def barrier():
         if world > 1:
@@ -335,7 +349,7 @@ def main():
     launch = vdb.index.last_launch()
     rechecked = launch["rechecked_queries"]
     n_launch = max(1, launch.get("scan_launches", 1))       # the tile scan covers a large store in several launches: one entry each
-    shard_ms = searcher.timings() if world > 1 else []
+    shard_ms = searcher.timings() if (world > 1 and not replicate) else []
     searcher.timing = False                                   # (the legs below are not broken down: no events to create)
 
     # ---- sustained: the same step, looped for >= args.sustain seconds (the chip settles at its steady-state clock) ------
@@ -445,6 +459,8 @@ def main():
     # which is what `rocprofv3 --stats` averages too
     knn_launch_avg = float(np.mean(knn_ms)) if knn_ms else float("nan")
     knn_avg = knn_launch_avg * n_launch
+    if replicate:
+        Q = B                                                           # a replica scans only its own clips
     flops = 2.0 * Q * (hi - lo) * DIM                                   # algorithmic FLOPs of one scan launch
     f16 = args.store_dtype == "f16"
     esz = 2.0 if f16 else 4.0
@@ -469,18 +485,33 @@ def main():
     logmel_kind = fe.last_logmel_kind()
     lm_avg = float(np.mean(lm_ms)) if lm_ms else float("nan")
     pp_avg = float(np.mean(pp_ms)) if pp_ms else float("nan")
-    # per-segment algorithmic work of the two embedding kernels: unfolded 400-tap real DFT of 201 bins
-    # x 200 frames (re + im) + mel 201 x 80 per frame; projection 200 x 80 x 512 per segment
-    lm_flops = n_segments * (201 * 200 * 400 * 2 * 2 + 200 * 201 * 80 * 2)
-    pp_flops = n_segments * (200 * 80 * DIM * 2)
-    lm_bytes = n_segments * (32000 * 4 + 200 * 80 * 4)
+    # Work of the two embedding kernels.  Algorithmic bytes: every clip sample once + the log-mel rows written
+    # (log-mel); the rows read + the embeddings written (projection).  FLOPs EXECUTED depend on the kernel that ran: the radix FFT
+    # (k_logmel_fft_clip: packed 200-point complex FFT ~7.6 k + real split 2 k + power 0.6 k + sparse mel 0.8 k = ~11 kFLOP per
+    # transformed frame, frames that overlapping segments share transformed once) or the DFT-as-GEMM (k_logmel_h[_clip]: 201 bins x
+    # 400 taps x (re, im) x 2 x 3 split products + the mel GEMM per transformed frame).
+    segs_per_clip = n_segments / max(1, B)
+    frames_per_seg = 200
+    if logmel_kind.startswith("clip_frames"):
+        n_transforms = int(B * ((segs_per_clip - 1) * 100 + frames_per_seg - 3) + 3 * n_segments)       # interior frames once per clip + 3 edge frames per segment
+    else:
+        n_transforms = n_segments * frames_per_seg
+    if logmel_kind == "clip_frames_fft":
+        lm_name, lm_flops, lm_peak, lm_bound = "k_seg_stats+k_logmel_fft_clip", n_transforms * 11000, PEAK_VALU_F32_TFLOPS, "valu"
+    else:
+        lm_name = "k_seg_stats+k_logmel_h_clip" if logmel_kind == "clip_frames" else "k_logmel_h"
+        lm_flops, lm_peak, lm_bound = n_transforms * (201 * 400 * 2 * 2 * 3 + 201 * 80 * 2 * 3), PEAK_MFMA_F16_TFLOPS, "mfma"
+    pp_flops = n_segments * (200 * 80 * DIM * 2) * 3                                 # three split-f16 products per fp32 product
+    n_samples = int(batches[0][3][-1]) if args.workload != "fixed" else B * 64000
+    lm_bytes = n_samples * 4 + n_segments * (200 * 80 * 4)
     pp_bytes = n_segments * (200 * 80 * 4) + B * DIM * 4
 
-    def kroof(ms, fl, by):
+    def kroof(ms, fl, by, bound, peak):
         tf = fl / (ms * 1e-3) / 1e12
-        return {"kernel_ms": round(ms, 4), "bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_MFMA_F16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(tf / PEAK_MFMA_F16_TFLOPS, 4), "flops_per_launch": fl, "algorithmic_bytes_per_launch": by,
-                "hbm_GBps_algorithmic": round(by / (ms * 1e-3) / 1e9, 1)}
+        gbs = by / (ms * 1e-3) / 1e9
+        return {"kernel_ms": round(ms, 4), "bound": bound, "flops_executed_per_launch": fl, "achieved": round(tf, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(tf / peak, 4), "algorithmic_bytes_per_launch": by,
+                "hbm_GBps_algorithmic": round(gbs, 1), "frac_hbm": round(gbs / PEAK_HBM_GBPS, 4)}
     if args.workload == "fixed":
         wl = f"{B} clips/GPU x 4 s @16 kHz (3 segments)"
     else:
@@ -493,8 +524,8 @@ def main():
         "dtype": dtype,
         "data": "synthetic",
         "config": {"workload": wl + f", F=512, levels=[1], cosine top-{TOP_K}, {n_total} x {DIM} {args.store_dtype} store "
-                                    f"row-sharded over {world} GPU(s)", "segments_per_gpu": n_segments,
-                   "clips_per_gpu": B, "db_rows": n_total, "dim": DIM, "k": TOP_K, "parallelism": f"shard{world}",
+                                    (f"replicated on each of {world} GPUs" if replicate else f"row-sharded over {world} GPU(s)"), "segments_per_gpu": n_segments,
+                   "clips_per_gpu": B, "db_rows": n_total, "dim": DIM, "k": TOP_K, "parallelism": (f"replicate{world}" if replicate else f"shard{world}"),
                    "planted_neighbours_found": planted_ok},
         "roofline": {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 2),
                      "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -505,10 +536,11 @@ def main():
                      "hbm_GBps_algorithmic": round(alg_bytes / (knn_avg * 1e-3) / 1e9, 1),
                      "queries_rejected_by_certificate_last_step": rechecked,
                      "launch": launch},
-        # (log-mel: the event pair spans k_seg_stats + k_logmel_h_clip when overlapping segments share their frames; the FLOP count stays
-        # the per-(segment, frame) formulation's -- the shared form issues ~2/3 of it at the benchmark's shape)
-        "kernels": {("k_seg_stats+k_logmel_h_clip" if logmel_kind == "clip_frames" else "k_logmel_h"): kroof(lm_avg, lm_flops, lm_bytes),
-                    "k_proj_pool": kroof(pp_avg, pp_flops, pp_bytes)},
+        # (log-mel: the event pair spans k_seg_stats and the log-mel kernel; `frac` is FLOPs executed against the pipe that executes
+        # them -- the fp32 vector ALU for the FFT kernel, the f16 matrix pipe otherwise --, `frac_hbm` the algorithmic bytes against HBM)
+        "kernels": {lm_name: kroof(lm_avg, lm_flops, lm_bytes, lm_bound, lm_peak),
+                    "k_proj_pool2": kroof(pp_avg, pp_flops, pp_bytes, "mfma", PEAK_MFMA_F16_TFLOPS)},
+        "frames_transformed_per_step": n_transforms,
         "kernels_measured": "HIP events over %d steps right after the timed region (the timed region carries the scan's events only)" % min(args.steps, 20),
         "logmel_kind": logmel_kind,
         "kernels_ms": {"k_logmel": round(lm_avg, 4), "k_proj_pool": round(pp_avg, 4), "scan": round(knn_avg, 4)},

@@ -125,6 +125,10 @@ int radad_knn_search_ex(radad_knn_t h, const void* q_dev, int q_dtype, int64_t n
 int radad_knn_search_begin(radad_knn_t h, const void* q_dev, int q_dtype, int64_t nq, int k, float* topk_lower_bounds_dev, void* stream);
 int radad_knn_search_finish(radad_knn_t h, const float* global_lower_bound_dev, float* out_dist_dev, int64_t* out_idx_dev,
                             double* out_key_dev, void* stream);
+/* Gives up a begun search (e.g. the exchange of the bounds between the shards failed): the handle accepts searches again.  No-op when
+ * nothing was begun.  While a search is begun, add / reserve / load / load_range fail with RADAD_EINVAL (its second half reads the
+ * rows live); _finish may run on another stream than _begin (it waits for _begin's device work through an event). */
+int radad_knn_search_abort(radad_knn_t h);
 /* host-buffer variant (what index.search(np.ndarray, k) does); synchronous */
 int radad_knn_search_host(radad_knn_t h, const float* q_host, int64_t nq, int k, float* out_dist_host,
                           int64_t* out_idx_host);
@@ -218,6 +222,10 @@ int radad_ivf_search(radad_ivf_t h, const float* q_dev, int64_t nq, int k, int n
                      int64_t* out_idx_dev, void* stream);      /* asynchronous on `stream` (the (query, probe) pairs are grouped by list on
                                                                     the device); only the first search after an add rebuilds the list layout
                                                                     synchronously */
+/* 1 if the most recent radad_ivf_search was answered by the exact scan of the index's flat store (26 < k <= 128): every row an IVF
+ * search could return AND the ones its probing would have missed -- a superset of faiss.IndexIVFFlat's answer (which holds only rows
+ * of the nprobe lists, vector_database.py:174-179), at the flat scan's cost, nprobe ignored.  0: the nprobe lists were scanned. */
+int radad_ivf_last_search_exact(radad_ivf_t h, int* exact_out);
 int radad_ivf_reconstruct(radad_ivf_t h, const int64_t* idx_dev, int64_t n, float* out_dev, void* stream);
 
 /* out[r] = the k-th largest of the groups x per_group values of row r, value (g, i) at in[(g n + r) per_group + i] -- the layout
@@ -289,6 +297,11 @@ int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_
  * [0, n_samples_total]; bit 1 non-monotone offsets; bit 2 more segments than n_samples_total / hop + n_clips.  A non-zero
  * value means the embeddings of that batch are NOT those of the intended clips. */
 int radad_embed_plan_flags(radad_embed_t h, int* flags_out);
+/* The same without waiting: the flags of the device-offset batches that have COMPLETED since the last report (OR-ed; each batch is
+ * reported once, by whichever of the two calls sees it first), and how many batches are still in flight.  A caller that queues batches
+ * back to back polls before each one (it never blocks behind the previous batch) and calls radad_embed_plan_flags once after the
+ * last. */
+int radad_embed_plan_flags_poll(radad_embed_t h, int* flags_out, int* batches_pending_out);
 /* Which log-mel kernel the most recent embedding call took: 0 = one transform per (segment, frame) (k_logmel_h, or k_logmel under
  * RADAD_LOGMEL_F32); 1, 2 = the frames overlapping segments share were transformed once per CLIP (chosen by the configuration --
  * segment hop a multiple of 160 samples and smaller than the segment, Slaney filter bank -- for calls that hand over clips;

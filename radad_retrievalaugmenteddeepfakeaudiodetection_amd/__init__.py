@@ -13,8 +13,8 @@ from .feature_extractor import MelProjectionFeatureExtractor, build_feature_extr
 from .pipeline import HotPathPipeline
 from .projection import ProjectionLayer
 from .radad_model import DetectionModel, RADADModel
-from .sharded import ShardedSearch, shard_bounds
+from .sharded import ReplicatedSearch, ShardedSearch, shard_bounds
 
 __all__ = ["Config", "AudioSegmenter", "TemporalPyramidPooling", "HipFlatIndex", "HipIVFFlatIndex", "VectorDatabase",
            "MelProjectionFeatureExtractor", "build_feature_extractor", "HotPathPipeline", "ProjectionLayer", "DetectionModel", "RADADModel",
-           "ShardedSearch", "shard_bounds"]
+           "ShardedSearch", "ReplicatedSearch", "shard_bounds"]

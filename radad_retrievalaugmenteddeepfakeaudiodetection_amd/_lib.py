@@ -68,6 +68,7 @@ SIGNATURES = {
                                       C.c_void_p]),
     "radad_knn_search_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "radad_knn_search_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "radad_knn_search_abort": (C.c_int, [C.c_void_p]),
     "radad_knn_last_scan_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_plane_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "radad_kth_largest": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
@@ -104,6 +105,7 @@ SIGNATURES = {
     "radad_ivf_assignments_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "radad_ivf_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "radad_ivf_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "radad_ivf_last_search_exact": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_ivf_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "radad_rownorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "radad_embed_create": (C.c_int, [C.POINTER(EmbedCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
@@ -116,6 +118,7 @@ SIGNATURES = {
     "radad_embed_forward_ex": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "radad_embed_forward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "radad_embed_plan_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "radad_embed_plan_flags_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "radad_embed_last_logmel_kind": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_embed_clip_chunks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
     "radad_embed_fft_clip_chunks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32)]),

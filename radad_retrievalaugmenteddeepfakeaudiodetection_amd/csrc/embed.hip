@@ -606,6 +606,7 @@ __global__ __launch_bounds__(PP2_THREADS, 2) void k_proj_pool2(ProjPoolParams p,
     // one 128-bit piece of a pass: clamp to max - 8, (x + 4) / 4 (feature_extraction_whisper.py:161-162) scaled by 2^12 -- one fma,
     // rounded once like (x + 4) / 4 . 2^12 --, split into the two f16 planes of buffer `buf`
     auto convert = [&](const PP2Item& it, const f32x4 (&raw)[PP2_RAW], float smax, int u, int buf) {
+        if (RADAD_DBG(p.debug, 64)) { asm volatile("" : : "v"(raw[u])); return; }
         const int i = u * PP2_THREADS + tid;
         const int fr = i / (N_MELS / 4), c4 = i % (N_MELS / 4);
         const int tt = it.f0 + fr;
@@ -653,6 +654,7 @@ __global__ __launch_bounds__(PP2_THREADS, 2) void k_proj_pool2(ProjPoolParams p,
         // pooling of one accumulator tile: acc[r] = feature feat[nt] of frame tfirst + (r&3) + 8(r>>2) + 4lh, before the scale and the bias
         auto pool_tile = [&](int nt, const f32x16& acc, int tfirst, int tlast) {
             if (!active[nt]) return;
+            if (RADAD_DBG(p.debug, 32)) { asm volatile("" : : "v"(acc)); return; }
             for (int b = 0; b < nbins; ++b) {
                 const int lo = s_lo[b], hi = s_hi[b];
                 if (hi <= tfirst || lo >= tlast) continue;        // wave-uniform
@@ -703,9 +705,11 @@ __global__ __launch_bounds__(PP2_THREADS, 2) void k_proj_pool2(ProjPoolParams p,
                     for (int st = 0; st < 5; ++st) {
                         const f16x8 ah = *reinterpret_cast<const f16x8*>(slm_h + aoff + st * 16);
                         const f16x8 al = *reinterpret_cast<const f16x8*>(slm_l + aoff + st * 16);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[nt][st], acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[nt][st], acc[nt], 0, 0, 0);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[nt][st], acc[nt], 0, 0, 0);
+                        if (!RADAD_DBG(p.debug, 16)) {
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh[nt][st], acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl[nt][st], acc[nt], 0, 0, 0);
+                            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh[nt][st], acc[nt], 0, 0, 0);
+                        } else asm volatile("" : "+v"(acc[nt]) : "v"(ah), "v"(al));
                         // (fences only around the inserted blocks: elsewhere hipcc keeps the fragment reads two k-steps ahead of their MFMAs)
                         if (nt == 0 && st == 0 && nxt.valid) {
                             __builtin_amdgcn_sched_barrier(0);
@@ -1107,9 +1111,13 @@ struct radad_embed_s {
     size_t pin_cap[2] = {0, 0};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     int pin_next = 0;
-    int* plan_flags_host = nullptr;      // pinned: what k_build_plan repaired in the most recent device-offset batch
-    hipEvent_t plan_flags_ev = nullptr;
-    bool plan_flags_pending = false;
+    // what k_build_plan repaired in the device-offset batches: a ring of pinned words, one per batch in flight, so that a caller can
+    // ask without waiting (radad_embed_plan_flags_poll) and no batch's report is overwritten by the next one's
+    static constexpr int PLAN_RING = 4;
+    int* plan_flags_host = nullptr;      // [PLAN_RING] pinned
+    hipEvent_t plan_flags_ev[PLAN_RING] = {nullptr, nullptr, nullptr, nullptr};
+    bool plan_flags_pending[PLAN_RING] = {false, false, false, false};
+    int plan_flags_next = 0, plan_flags_accum = 0;
     EventRing prof_logmel, prof_pool;
     std::mutex mu;
 };
@@ -1515,7 +1523,8 @@ int radad_embed_destroy(radad_embed_t h) {
             if (h->pin_ev[i]) (void)hipEventDestroy(h->pin_ev[i]);
         }
         if (h->plan_flags_host) (void)hipHostFree(h->plan_flags_host);
-        if (h->plan_flags_ev) (void)hipEventDestroy(h->plan_flags_ev);
+        for (int i = 0; i < radad_embed_s::PLAN_RING; ++i)
+            if (h->plan_flags_ev[i]) (void)hipEventDestroy(h->plan_flags_ev[i]);
         h->misc.release();
         h->prof_logmel.destroy();
         h->prof_pool.destroy();
@@ -1613,14 +1622,36 @@ int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_
     h->plan_on_device = true;
     h->plan_nseg = seg_cap;
     if ((rc = embed_run(h, wave_dev, n_clips, seg_cap, false, out_dev, out_dtype, (const int*)h->n_seg_dev.p, st))) return rc;
-    // what k_build_plan had to repair travels to pinned host memory behind the batch (radad_embed_plan_flags waits for it)
+    // what k_build_plan had to repair travels to pinned host memory behind the batch (radad_embed_plan_flags[_poll] read it)
     if (!h->plan_flags_host) {
-        RADAD_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->plan_flags_host), sizeof(int), hipHostMallocDefault));
-        RADAD_HIP_CHECK(hipEventCreateWithFlags(&h->plan_flags_ev, hipEventDisableTiming));
+        RADAD_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&h->plan_flags_host), radad_embed_s::PLAN_RING * sizeof(int), hipHostMallocDefault));
+        for (int i = 0; i < radad_embed_s::PLAN_RING; ++i) RADAD_HIP_CHECK(hipEventCreateWithFlags(&h->plan_flags_ev[i], hipEventDisableTiming));
     }
-    RADAD_HIP_CHECK(hipMemcpyAsync(h->plan_flags_host, (const int*)h->n_seg_dev.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-    RADAD_HIP_CHECK(hipEventRecord(h->plan_flags_ev, st));
-    h->plan_flags_pending = true;
+    const int slot = h->plan_flags_next;
+    if (h->plan_flags_pending[slot]) {           // four unread batches in flight: the oldest is folded into the running report first
+        RADAD_HIP_CHECK(hipEventSynchronize(h->plan_flags_ev[slot]));
+        h->plan_flags_accum |= h->plan_flags_host[slot];
+        h->plan_flags_pending[slot] = false;
+    }
+    RADAD_HIP_CHECK(hipMemcpyAsync(h->plan_flags_host + slot, (const int*)h->n_seg_dev.p + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+    RADAD_HIP_CHECK(hipEventRecord(h->plan_flags_ev[slot], st));
+    h->plan_flags_pending[slot] = true;
+    h->plan_flags_next = (slot + 1) % radad_embed_s::PLAN_RING;
+    return RADAD_OK;
+}
+
+static int plan_flags_collect(radad_embed_t h, bool wait, int* flags_out, int* pending_out) {
+    int pending = 0;
+    for (int i = 0; i < radad_embed_s::PLAN_RING; ++i) {
+        if (!h->plan_flags_pending[i]) continue;
+        if (wait) RADAD_HIP_CHECK(hipEventSynchronize(h->plan_flags_ev[i]));
+        else if (hipEventQuery(h->plan_flags_ev[i]) != hipSuccess) { (void)hipGetLastError(); ++pending; continue; }
+        h->plan_flags_accum |= h->plan_flags_host[i];
+        h->plan_flags_pending[i] = false;
+    }
+    *flags_out = h->plan_flags_accum;
+    h->plan_flags_accum = 0;                   // reported once
+    if (pending_out) *pending_out = pending;
     return RADAD_OK;
 }
 
@@ -1628,12 +1659,14 @@ int radad_embed_plan_flags(radad_embed_t h, int* flags_out) {
     RADAD_REQUIRE(h && flags_out, "radad_embed_plan_flags: NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
-    *flags_out = 0;
-    if (!h->plan_flags_pending) return RADAD_OK;
-    RADAD_HIP_CHECK(hipEventSynchronize(h->plan_flags_ev));
-    *flags_out = *h->plan_flags_host;
-    h->plan_flags_pending = false;           // reported once
-    return RADAD_OK;
+    return plan_flags_collect(h, true, flags_out, nullptr);
+}
+
+int radad_embed_plan_flags_poll(radad_embed_t h, int* flags_out, int* batches_pending_out) {
+    RADAD_REQUIRE(h && flags_out, "radad_embed_plan_flags_poll: NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    return plan_flags_collect(h, false, flags_out, batches_pending_out);
 }
 
 int radad_embed_clip_chunks(int n_segments, int frames_per_segment, int hop_frames, int32_t* out5) {

@@ -2034,6 +2034,7 @@ struct radad_knn_s {
     int* host_count = nullptr;   // pinned [2][8]: rejected queries, sum of candidates, rejections by reason x 4
     int* host_count_dev = nullptr;   // the same memory as the device sees it
     hipEvent_t ev_count[2] = {nullptr, nullptr}, ev_done = nullptr;
+    hipEvent_t ev_begun = nullptr;      // end of radad_knn_search_begin's device work: _finish waits for it (it may run on another stream)
     bool count_pending[2] = {false, false}, done_recorded = false;
     int64_t count_nq[2] = {0, 0};    // batch size of the search a slot belongs to
     uint64_t search_seq = 0;     // certified searches so far
@@ -2315,7 +2316,8 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
         if (hipHostMalloc(reinterpret_cast<void**>(&h->host_count), 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_count[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_count[1], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_begun, hipEventDisableTiming) != hipSuccess) {
             radad_set_error("radad_knn_create: pinned counter / events could not be created");
             radad_knn_destroy(h);
             return RADAD_EHIP;
@@ -2349,6 +2351,7 @@ int radad_knn_destroy(radad_knn_t h) {
         if (h->host_count) (void)hipHostFree(h->host_count);
         for (int i = 0; i < 2; ++i) if (h->ev_count[i]) (void)hipEventDestroy(h->ev_count[i]);
         if (h->ev_done) (void)hipEventDestroy(h->ev_done);
+        if (h->ev_begun) (void)hipEventDestroy(h->ev_begun);
         h->prof.destroy();
     }
     delete h;
@@ -2363,6 +2366,7 @@ int radad_knn_reserve(radad_knn_t h, int64_t capacity) {
     RADAD_REQUIRE(h, "NULL handle");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
+    RADAD_REQUIRE(!h->pending.valid, "radad_knn_reserve: a begun search (radad_knn_search_begin) must be finished or aborted before the store changes");
     if (capacity <= h->capacity) return RADAD_OK;
     RADAD_HIP_CHECK(hipDeviceSynchronize());
     return knn_realloc(h, capacity);
@@ -2376,6 +2380,8 @@ int radad_knn_add(radad_knn_t h, const float* rows_dev, int64_t n, void* stream)
     RADAD_REQUIRE(h->ntotal + n < (int64_t)IDX_SENTINEL, "radad_knn_add: more than 2^31-2 rows per store (shard it)");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
+    // (the second half of a begun search reads rows / ntotal live while its candidate ids date from the first half)
+    RADAD_REQUIRE(!h->pending.valid, "radad_knn_add: a begun search (radad_knn_search_begin) must be finished or aborted before the store changes");
     hipStream_t st = (hipStream_t)stream;
     if (h->ntotal + n > h->capacity) {
         RADAD_HIP_CHECK(hipStreamSynchronize(st));   // the old buffers may still be in use on `st`
@@ -3022,7 +3028,15 @@ int radad_knn_search_begin(radad_knn_t h, const void* q_dev, int q_dtype, int64_
     SearchCtx c;
     int rc = knn_search_phase1(h, q_dev, q_dtype, nq, k, KNN_MARGIN, kth_lower_bound_dev, (hipStream_t)stream, &c);
     if (rc) return rc;
+    RADAD_HIP_CHECK(hipEventRecord(h->ev_begun, (hipStream_t)stream));
     h->pending = c;
+    return RADAD_OK;
+}
+
+int radad_knn_search_abort(radad_knn_t h) {
+    RADAD_REQUIRE(h, "NULL handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->pending.valid = false;                 // (the workspace of the abandoned first half is simply reused by the next search)
     return RADAD_OK;
 }
 
@@ -3035,6 +3049,7 @@ int radad_knn_search_finish(radad_knn_t h, const float* global_lower_bound_dev, 
     RADAD_REQUIRE(h->pending.valid, "radad_knn_search_finish: no search was begun on this handle");
     const SearchCtx c = h->pending;
     h->pending.valid = false;
+    RADAD_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->ev_begun, 0));       // the scan of _begin (no-op on the same stream)
     return knn_search_phase2(h, c, global_lower_bound_dev, out_dist_dev, out_idx_dev, out_key_dev, (hipStream_t)stream);
 }
 
@@ -3269,6 +3284,7 @@ int snap_load_range(radad_knn_t h, const char* path, int64_t row0, int64_t n_row
     RADAD_REQUIRE(row0 >= 0 && n_rows >= 0 && row0 + n_rows <= hd.ntotal, "radad_knn_load_range: rows outside the snapshot");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
+    RADAD_REQUIRE(!h->pending.valid, "radad_knn_load: a begun search (radad_knn_search_begin) must be finished or aborted before the store changes");
     RADAD_HIP_CHECK(hipDeviceSynchronize());
     h->ntotal = 0;
     h->hi_rows = 0; h->stat_rows = 0;      // the hi plane and the statistics describe the old contents

@@ -133,8 +133,9 @@ class MelProjectionFeatureExtractor:
             if n_clips < 0:
                 raise ValueError("clip_offsets must hold at least one entry")
             # device offsets cannot be checked here without a synchronisation: the plan kernel clamps them (no out-of-bounds
-            # read whatever the tensor holds) and flags what it repaired; the PREVIOUS batch's flags have long landed
-            self.check_device_plan(what="the previous device-offset batch")
+            # read whatever the tensor holds) and flags what it repaired.  Earlier batches that have COMPLETED are reported here
+            # without waiting (a caller may queue batches back to back); check_device_plan() after the last batch waits for the rest
+            self.check_device_plan(what="an earlier device-offset batch", wait=False)
             out = torch.empty((n_clips, self.output_dim), device=wave.device, dtype=out_dtype)
             with torch.cuda.device(wave.device):
                 _lib.check(self._lib.radad_embed_forward_dev(self._h, wave.data_ptr(), offs.data_ptr(), n_clips, wave.numel(),
@@ -152,12 +153,16 @@ class MelProjectionFeatureExtractor:
                        "radad_embed_forward")
         return out
 
-    def check_device_plan(self, what="the last device-offset batch"):
-        """ValueError if the segment-plan kernel had to repair the device-resident clip offsets of the most recent
-        embed_clips(wave, <CUDA offsets>) call (the host-offset path raises up front, as segmenter.py:18-19 does for bad
-        input).  Waits for that batch."""
-        f = C.c_int()
-        _lib.check(self._lib.radad_embed_plan_flags(self._h, C.byref(f)), "radad_embed_plan_flags")
+    def check_device_plan(self, what="a device-offset batch", wait=True):
+        """ValueError if the segment-plan kernel had to repair the device-resident clip offsets of an embed_clips(wave, <CUDA
+        offsets>) call since the last report (the host-offset path raises up front, as segmenter.py:18-19 does for bad input).
+        wait=True (the default: call it after the LAST batch) waits for every batch in flight; wait=False reports only batches
+        that have completed and never blocks -- embed_clips does that before each launch."""
+        f, pend = C.c_int(), C.c_int()
+        if wait:
+            _lib.check(self._lib.radad_embed_plan_flags(self._h, C.byref(f)), "radad_embed_plan_flags")
+        else:
+            _lib.check(self._lib.radad_embed_plan_flags_poll(self._h, C.byref(f), C.byref(pend)), "radad_embed_plan_flags_poll")
         if f.value:
             why = [m for b, m in ((1, "offsets outside the wave buffer"), (2, "offsets not non-decreasing"),
                                   (4, "more segments than the wave buffer can hold")) if f.value & b]

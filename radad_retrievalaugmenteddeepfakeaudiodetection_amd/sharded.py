@@ -79,9 +79,10 @@ class ShardedSearch:
         self.merge = merge or hip_merge
         self.uneven = bool(uneven)
         self.exchange = exchange
-        # bounded = (begin, finish): begin(q [Q,D], k) -> float32 [Q, k] lower bounds of the exact scores of this shard's k best rows
-        # (or [Q]: of its k-th best alone); finish(global_lb [Q]) -> (dist [Q,k] (float64 keys), gid [Q,k]), rows short of k are
-        # -1 filled.  Same on every rank.
+        # bounded = (begin, finish[, abort]): begin(q [Q,D], k) -> float32 [Q, k] lower bounds of the exact scores of this shard's k best
+        # rows (or [Q]: of its k-th best alone); finish(global_lb [Q] or None) -> (dist [Q,k] (float64 keys), gid [Q,k]), rows short of
+        # k are -1 filled; abort() gives the begun search up when the exchange fails (without it finish(None) is called).  Same on
+        # every rank.
         self.bounded = bounded
         self.timing = bool(timing)       # record (collective_ms, rerank_ms) of every search (CUDA events; read with timings())
         self._events = []
@@ -186,18 +187,26 @@ class ShardedSearch:
         with timed("c"):
             q_all = self._all_gather(q_local)
         if self.bounded is not None:
-            begin, finish = self.bounded
+            begin, finish = self.bounded[0], self.bounded[1]
+            abort = self.bounded[2] if len(self.bounded) > 2 else None
             lb = begin(q_all, k)
-            with timed("c"):
-                if lb.dim() == 2:      # the k best of every shard: the k-th largest of the union bounds the global k-th best
-                    allb = self._all_gather(lb).view(self.world, lb.shape[0], lb.shape[1])
-                    if allb.is_cuda:
+            # Between begin and finish the shard holds a begun search: whatever goes wrong in the exchange (a collective that throws,
+            # a bound kernel that refuses its shape), the second half must still run -- or be given up -- or every later search on
+            # this index fails with "has not been finished".
+            try:
+                with timed("c"):
+                    if lb.dim() == 2:      # the k best of every shard: the k-th largest of the union bounds the global k-th best
+                        allb = self._all_gather(lb).view(self.world, lb.shape[0], lb.shape[1])
                         from .vector_database import HipFlatIndex
-                        lb = HipFlatIndex.global_bound(allb, k)
+                        lb = HipFlatIndex.global_bound(allb, k)       # (torch.topk on the CPU or beyond the kernel's 1280 values per query)
                     else:
-                        lb = torch.topk(allb.permute(1, 0, 2).reshape(lb.shape[0], -1), k, dim=1).values[:, k - 1].contiguous()
+                        lb = self._all_reduce_max(lb)
+            except BaseException:
+                if abort is not None:
+                    abort()
                 else:
-                    lb = self._all_reduce_max(lb)
+                    finish(None)                                      # (this shard's own top k: a valid, if unbounded, second half)
+                raise
             with timed("r"):
                 d_loc, i_loc = finish(lb)
         else:
@@ -217,3 +226,31 @@ class ShardedSearch:
         if rec:
             self._events.append((coll_ev, rr_ev, coll_ev[-1][1]))
         return md[:qr], mi[:qr]
+
+
+class ReplicatedSearch:
+    """The other way to use G GPUs (SURVEY 8e's tuning option; the reference is single-GPU, vector_database.py:23): every rank holds
+    the WHOLE store and searches only its own queries -- no collective in the data path, a rank's step is the one-GPU step.  Every
+    BASELINE store fits one 288 GB MI355X (1 M x 512: 3 GB with its f16 plane; 10 M x 512: 30 GB; 50 M x 256 fp16: 26 GB); sharding
+    (ShardedSearch, north_star's partitioning) is for stores that do not, and costs every rank the scan of ALL queries plus G re-ranks.
+    Same call surface as ShardedSearch: search(q_local, k) -> this rank's rows; return_all=True gathers every rank's rows (rank-major;
+    the only collective, and not part of a search)."""
+
+    def __init__(self, local_search: Callable, group=None):
+        import torch.distributed as dist
+        self.local_search = local_search
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.timing = False
+        self._gather = ShardedSearch(None, 0, group=group)._all_gather
+
+    def timings(self):
+        return []
+
+    def search(self, q_local, k: int, return_all: bool = False):
+        d, i = self.local_search(q_local, k)
+        d = d.float()
+        if not return_all or self.world == 1:
+            return d, i
+        return self._gather(d), self._gather(i)

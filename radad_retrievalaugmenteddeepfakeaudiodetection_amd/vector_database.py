@@ -182,6 +182,8 @@ class HipFlatIndex:
         bound of the exact k-th best score over all shards"""
         import torch
         G, nq, kk = lb_all.shape
+        if G * kk > HipFlatIndex.KTH_MAX_VALUES or not lb_all.is_cuda:     # beyond the selection kernel's reach (8 ranks x k > 160): torch
+            return torch.topk(lb_all.permute(1, 0, 2).reshape(nq, -1).float(), int(k), dim=1).values[:, int(k) - 1].contiguous()
         flat = lb_all.contiguous().float()                 # [G][nq][k] as gathered: the kernel reads that layout
         out = torch.empty((nq,), device=flat.device, dtype=torch.float32)
         with torch.cuda.device(flat.device):
@@ -194,6 +196,8 @@ class HipFlatIndex:
         shards' search_begin bounds; None = this shard's own top k), then the exact kernel for uncertified queries.
         -> (D, I[, K64]) as search_device; with a bound a row may hold fewer than k real entries (-1 filled)."""
         import torch
+        if getattr(self, "_begun", None) is None:
+            raise ValueError("search_finish: no search was begun on this index (search_begin first; a begun search is finished once)")
         q, k = self._begun
         self._begun = None
         D = torch.empty((q.shape[0], k), device=q.device, dtype=torch.float32)
@@ -209,6 +213,13 @@ class HipFlatIndex:
                                                          I.data_ptr(), K64.data_ptr() if return_f64 else None,
                                                          _lib.stream_ptr(q.device)), "radad_knn_search_finish")
         return (D, I, K64) if return_f64 else (D, I)
+
+    def search_abort(self):
+        """gives up a begun search (the exchange between the shards failed): the index accepts searches again"""
+        self._begun = None
+        _lib.check(self._lib.radad_knn_search_abort(self._h), "radad_knn_search_abort")
+
+    KTH_MAX_VALUES = 1280        # radad_kth_largest: groups x per_group values per query (csrc/knn.hip KTH_PER_LANE x 64)
 
     def reconstruct_batch(self, idx):
         """idx: int64 CUDA tensor of any shape -> [*idx.shape, d]; negative ids give zero rows."""
@@ -376,6 +387,14 @@ class HipIVFFlatIndex:
         with torch.cuda.device(q.device):
             _lib.check(self._lib.radad_ivf_search(self._h, q.data_ptr(), q.shape[0], int(k), int(self.nprobe), D.data_ptr(), I.data_ptr(),
                                                   _lib.stream_ptr(q.device)), "radad_ivf_search")
+        ex = C.c_int()
+        _lib.check(self._lib.radad_ivf_last_search_exact(self._h, C.byref(ex)))
+        self.last_search_exact = bool(ex.value)
+        if self.last_search_exact and not getattr(self, "_warned_exact", False):
+            self._warned_exact = True
+            logging.getLogger(__name__).warning(
+                "HipIVFFlatIndex: k=%d > 26 is answered by the exact scan of all rows (a superset of the nprobe=%d lists' rows, at the "
+                "flat search's cost); faiss.IndexIVFFlat would return rows of the probed lists only", k, self.nprobe)
         return D, I
 
     def search(self, x, k: int):

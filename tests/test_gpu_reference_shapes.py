@@ -288,13 +288,30 @@ def test_device_offsets_outside_the_wave_buffer_are_clamped_and_reported(gpu):
         # clips whose own offsets were fine are embedded as before (clip 1 in all four cases)
         if why == "outside the wave buffer":
             assert torch.equal(out[1], ref[1])
-    # the flag is reported once; the next good batch is clean, and a bad batch is also reported by the NEXT call
-    fe.embed_clips(wave, torch.tensor([0, n, 2 * n, 3 * n, 40 * n], device=gpu, dtype=torch.int64))
-    with pytest.raises(ValueError, match="previous device-offset batch"):
+    # the flag is reported once; the next good batch is clean, and a bad batch that has COMPLETED is also reported by the next call
+    # (which polls and never waits: ADVICE r3 -- it used to block behind the previous batch)
+    bad = torch.tensor([0, n, 2 * n, 3 * n, 40 * n], device=gpu, dtype=torch.int64)
+    fe.embed_clips(wave, bad)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="an earlier device-offset batch"):
         fe.embed_clips(wave, good)
     out = fe.embed_clips(wave, good)
     fe.check_device_plan()
     assert torch.equal(out, ref)
+    # six batches queued back to back (more than the ring of report words holds), the first one bad: nothing is lost, the report
+    # comes once -- from a poll of a later call if that batch happens to be complete by then, from the final check otherwise
+    seen = 0
+    for i in range(6):
+        try:
+            fe.embed_clips(wave, bad if i == 0 else good)
+        except ValueError:
+            seen += 1
+    try:
+        fe.check_device_plan()
+    except ValueError:
+        seen += 1
+    assert seen == 1
+    fe.check_device_plan()                                             # reported once
 
 
 def test_kth_largest_kernel(gpu):

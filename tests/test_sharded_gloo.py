@@ -122,3 +122,106 @@ def test_sharded_search_with_a_global_bound(world, metric, n, nq_locals, k, exch
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), metric, n, nq_locals, 16, k, exchange, out, form), nprocs=world, join=True)
     assert dict(out) == {r: True for r in range(world)}
+
+
+def _worker_failing_exchange(rank, world, port, out):
+    """the bound exchange throws on every rank: the begun search must be given up (abort) and the error re-raised; the index
+    stand-in then accepts the next search (a shard was left unusable with 'has not been finished')"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import sharded, vector_database
+    state = {"begun": False, "aborted": 0, "finished": 0}
+
+    def begin(q, k):
+        assert not state["begun"], "search_begin: the previous begin on this handle has not been finished"
+        state["begun"] = True
+        return torch.zeros((len(q), k))
+
+    def finish(glb):
+        state["begun"] = False
+        state["finished"] += 1
+        return torch.zeros((4, 3), dtype=torch.float64), torch.zeros((4, 3), dtype=torch.int64)
+
+    def abort():
+        state["begun"] = False
+        state["aborted"] += 1
+
+    real = vector_database.HipFlatIndex.global_bound
+    boom = {"on": True}
+
+    def global_bound(allb, k):
+        if boom["on"]:
+            raise ValueError("radad_kth_largest: bad shape")
+        return real(allb, k)
+
+    vector_database.HipFlatIndex.global_bound = staticmethod(global_bound)
+    merge = lambda m, d, i, kk: (d[0].float(), i[0])
+    ok = True
+    for use_abort in (True, False):
+        s = sharded.ShardedSearch(None, 1, merge=merge, bounded=(begin, finish, abort) if use_abort else (begin, finish))
+        boom["on"] = True
+        try:
+            s.search(torch.zeros((2, 8)), 3)
+            ok = False
+        except ValueError:
+            pass
+        ok = ok and not state["begun"]
+        boom["on"] = False
+        d, i = s.search(torch.zeros((2, 8)), 3)           # the index accepts the next search
+        ok = ok and d.shape == (2, 3)
+    out[rank] = bool(ok and state["aborted"] == 1 and state["finished"] == 3)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failed_bound_exchange_does_not_leave_the_shard_begun():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_failing_exchange, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_global_bound_beyond_the_selection_kernel_falls_back_to_topk():
+    """8 ranks x k = 200 > the 1280 values radad_kth_largest takes per query (and CPU tensors): torch.topk instead of an error"""
+    sys.path.insert(0, ROOT)
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.vector_database import HipFlatIndex
+    g = torch.Generator().manual_seed(3)
+    lb = torch.randn((8, 5, 200), generator=g)
+    got = HipFlatIndex.global_bound(lb, 200)
+    ref = torch.sort(lb.permute(1, 0, 2).reshape(5, -1), dim=1, descending=True).values[:, 199]
+    assert torch.equal(got, ref)
+    idx = HipFlatIndex.__new__(HipFlatIndex)
+    idx._begun = None
+    with pytest.raises(ValueError, match="no search was begun"):
+        idx.search_finish()
+
+
+def _worker_replicated(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import radad_oracle as O, synth
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import ReplicatedSearch
+    db = synth.rows(0, 777, 16, 4321)                    # every rank holds the whole store
+    q_all = synth.rows(0, 4 * world, 16, 977)
+    q_local = torch.from_numpy(q_all[4 * rank:4 * rank + 4])
+    local = lambda q, k: tuple(torch.from_numpy(x) for x in O.knn(db, q.numpy(), k, "IP"))
+    s = ReplicatedSearch(local)
+    d, i = s.search(q_local, 9)
+    da, ia = s.search(q_local, 9, return_all=True)
+    od, oi = O.knn(db, q_all, 9, "IP")
+    out[rank] = bool(np.array_equal(i.numpy(), oi[4 * rank:4 * rank + 4]) and np.array_equal(ia.numpy(), oi)
+                     and np.allclose(da.numpy(), od, rtol=1e-6) and d.shape == (4, 9) and (s.world, s.rank) == (world, rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_replicated_store_returns_the_unsharded_result():
+    """--parallelism replicate: every rank searches its own queries against the whole store; gathered, that IS the unsharded search"""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_replicated, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}
