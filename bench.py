@@ -111,14 +111,15 @@ def main():
                          "clips (log-normal, mean ~4.3 s, clipped to [0.5, 20] s) cut by the segmenter rule")
     ap.add_argument("--scan", choices=["auto", "f32"], default="auto",
                     help="auto = large batches take the certified single-product f16 scan on the hi plane of the fp32 store "
-                         "(float64 re-rank from the fp32 rows); f32 = the fp32-MFMA tile kernel only (RADAD_KNN_HI=0)")
+                         "(float64 re-rank from the fp32 rows); f32 = the fp32-MFMA tile kernel only (config.knn_hi_plane = False)")
+    ap.add_argument("--logmel", choices=["fft", "gemm"], default="fft",
+                    help="fft = the shared-frame log-mel as a radix FFT on the vector ALU (k_logmel_fft_clip, default); gemm = the round-3 "
+                         "DFT-as-GEMM on the f16 matrix pipe (k_logmel_h_clip), for A/B")
     ap.add_argument("--store-dtype", choices=["f32", "f16"], default="f32",
                     help="f16 = the reference's use_float16 knob (fp16 rows); NOT the headline configuration")
     ap.add_argument("--embed-dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16 = embeddings emitted and searched as bfloat16 (BASELINE config 5); NOT the headline configuration")
     args = ap.parse_args()
-    if args.scan == "f32":
-        os.environ["RADAD_KNN_HI"] = "0"       # read by radad_knn_create
 
     import numpy as np
     import torch
@@ -189,7 +190,8 @@ def main():
 
     cfg = R.Config()
     cfg.update(device=dev, tpp_levels=[1], tpp_pooling_type="max", feature_dim=DIM, vector_db_index_type="IP",
-               use_float16=(args.store_dtype == "f16"))
+               use_float16=(args.store_dtype == "f16"), knn_hi_plane=(False if args.scan == "f32" else None),
+               melproj_logmel_fft=(args.logmel == "fft"))
     fe = R.MelProjectionFeatureExtractor(cfg)
     B = args.clips
     n_total = args.db_rows
@@ -523,7 +525,7 @@ def main():
         "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": dtype,
         "data": "synthetic",
-        "config": {"workload": wl + f", F=512, levels=[1], cosine top-{TOP_K}, {n_total} x {DIM} {args.store_dtype} store "
+        "config": {"workload": wl + f", F=512, levels=[1], cosine top-{TOP_K}, {n_total} x {DIM} {args.store_dtype} store " +
                                     (f"replicated on each of {world} GPUs" if replicate else f"row-sharded over {world} GPU(s)"), "segments_per_gpu": n_segments,
                    "clips_per_gpu": B, "db_rows": n_total, "dim": DIM, "k": TOP_K, "parallelism": (f"replicate{world}" if replicate else f"shard{world}"),
                    "planted_neighbours_found": planted_ok},

@@ -72,6 +72,21 @@ int radad_knn_create(int dim, int metric, int device, int64_t id_base, radad_knn
 #define RADAD_STORE_F32 0
 #define RADAD_STORE_F16 1
 int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_t id_base, radad_knn_t* out);
+/* Kernel choices of a handle, for experiments and A/B measurements (every value returns the same results; only speed differs).
+ * Set them right after creation: HI_PLANE and CENTRE are refused once the f16 plane of the store has been built.
+ *   RADAD_KNN_OPT_HI_PLANE   1 (default) / 0: large batches scan the f16 "hi plane" of an fp32 store (certified scan + float64 re-rank)
+ *                            / every batch scans on the fp32 kernels (~8x slower 1024-query scans)
+ *   RADAD_KNN_OPT_CENTRE     -1 (default: decided per store from |mean|^2 / mean |y|^2) / 0 never / 1 always subtract the rows' column
+ *                            mean before rounding the plane
+ *   RADAD_KNN_OPT_SMALLQ_HI  1 (default) / 0: batches of <= 16 queries stream the f16 plane / the fp32 rows (twice the bytes)
+ *   RADAD_KNN_OPT_WIDE_MIN_Q smallest batch that takes the 256-query tile scan instead of the streaming kernels (default 17)
+ * The environment variables RADAD_KNN_HI, RADAD_KNN_CENTRE, RADAD_KNN_SMALLQ_HI, RADAD_WIDE_MIN_Q override the DEFAULTS of handles
+ * created while they are set (announced once per process on stderr); the product path never needs them. */
+#define RADAD_KNN_OPT_HI_PLANE 0
+#define RADAD_KNN_OPT_CENTRE 1
+#define RADAD_KNN_OPT_SMALLQ_HI 2
+#define RADAD_KNN_OPT_WIDE_MIN_Q 3
+int radad_knn_set_option(radad_knn_t h, int option, int value);
 int radad_knn_destroy(radad_knn_t h);
 int radad_knn_dim(radad_knn_t h, int* dim);
 int radad_knn_metric(radad_knn_t h, int* metric);
@@ -267,6 +282,19 @@ typedef struct radad_embed_s* radad_embed_t;
 /* mel_filters_host [201, 80] fp32 (bins x mels); proj_w_host [80, F] fp32; proj_b_host [F] fp32 */
 int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host, const float* proj_w_host,
                        const float* proj_b_host, int device, radad_embed_t* out);
+/* same with a choice of log-mel kernel (all give feature_extraction_whisper.py:135-168 per segment within the 1e-4 bar; for A/B
+ * measurements and parity tests): flags = 0 is radad_embed_create.
+ *   RADAD_EMBED_NO_SHARED_FRAMES  one transform per (segment, frame) even where overlapping segments share frames (k_logmel_h)
+ *   RADAD_EMBED_LOGMEL_F32        the folded DFT on the fp32 matrix pipe (k_logmel, ~2x slower than k_logmel_h)
+ *   RADAD_EMBED_LOGMEL_DFT_GEMM   shared frames as a DFT-as-GEMM on the f16 matrix pipe (k_logmel_h_clip) instead of the radix FFT on the
+ *                                 vector ALU (k_logmel_fft_clip, the default where the configuration allows sharing)
+ * The environment variables RADAD_LOGMEL_SHARED=0, RADAD_LOGMEL_F32=1, RADAD_LOGMEL_FFT=0 set the same bits for extractors created
+ * while they are set (announced once per process on stderr). */
+#define RADAD_EMBED_NO_SHARED_FRAMES 1
+#define RADAD_EMBED_LOGMEL_F32 2
+#define RADAD_EMBED_LOGMEL_DFT_GEMM 4
+int radad_embed_create_ex(const radad_embed_cfg* cfg, int flags, const float* mel_filters_host, const float* proj_w_host,
+                          const float* proj_b_host, int device, radad_embed_t* out);
 int radad_embed_destroy(radad_embed_t h);
 int radad_embed_output_dim(radad_embed_t h, int* dim);     /* sum(levels)*F  (pooling.py:119-122)    */
 int radad_embed_num_frames(radad_embed_t h, int* frames);   /* frames per segment                      */

@@ -19,6 +19,8 @@ Q_F32, Q_BF16 = 0, 1
 OUT_F32, OUT_BF16 = 0, 1
 MAX_LEVELS = 8
 KNN_MAX_K = 1024
+KNN_OPT_HI_PLANE, KNN_OPT_CENTRE, KNN_OPT_SMALLQ_HI, KNN_OPT_WIDE_MIN_Q = 0, 1, 2, 3
+EMBED_NO_SHARED_FRAMES, EMBED_LOGMEL_F32, EMBED_LOGMEL_DFT_GEMM = 1, 2, 4
 
 c_i64p = C.POINTER(C.c_int64)
 c_i32p = C.POINTER(C.c_int32)
@@ -55,6 +57,7 @@ SIGNATURES = {
     "radad_knn_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
     "radad_knn_create_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p)]),
     "radad_knn_destroy": (C.c_int, [C.c_void_p]),
+    "radad_knn_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "radad_knn_dim": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_metric": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_ntotal": (C.c_int, [C.c_void_p, c_i64p]),
@@ -110,6 +113,8 @@ SIGNATURES = {
     "radad_rownorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "radad_embed_create": (C.c_int, [C.POINTER(EmbedCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                      C.POINTER(C.c_void_p)]),
+    "radad_embed_create_ex": (C.c_int, [C.POINTER(EmbedCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.POINTER(C.c_void_p)]),
     "radad_embed_destroy": (C.c_int, [C.c_void_p]),
     "radad_embed_output_dim": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_embed_num_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),

@@ -50,6 +50,15 @@ class Config:
         self.melproj_padded_samples = 0     # 0: spectrogram of the segment itself; 480000: HF's 30 s padding
         self.melproj_seed = 20251003        # seed of the synthetic projection weights when no file is given
         self.melproj_weights_path = None    # optional .npz with 'w' [80,F] and 'b' [F]
+        # kernel choices (speed only, results unchanged; A/B measurements and parity tests): which log-mel kernel ...
+        self.melproj_share_frames = True    # frames that overlapping segments share are transformed once per clip
+        self.melproj_logmel_fft = True      # ... as a radix FFT on the vector ALU (False: DFT-as-GEMM on the f16 matrix pipe)
+        self.melproj_logmel_f32 = False     # True: the folded DFT on the fp32 matrix pipe (per segment)
+        # ... and which scan (None = the library's default): radad_knn_set_option
+        self.knn_hi_plane = None            # False: every batch scans on the fp32 kernels (no f16 plane)
+        self.knn_centre = None              # -1 / 0 / 1: decide per store / never / always centre the f16 plane
+        self.knn_smallq_hi = None           # False: batches of <= 16 queries stream the fp32 rows
+        self.knn_wide_min_q = None          # smallest batch on the 256-query tile scan (default 17)
 
     def update(self, **kwargs):
         """config.py:109-115."""

@@ -1295,6 +1295,13 @@ extern "C" {
 
 int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host, const float* proj_w_host,
                        const float* proj_b_host, int device, radad_embed_t* out) {
+    return radad_embed_create_ex(cfg, 0, mel_filters_host, proj_w_host, proj_b_host, device, out);
+}
+
+int radad_embed_create_ex(const radad_embed_cfg* cfg, int flags, const float* mel_filters_host, const float* proj_w_host,
+                          const float* proj_b_host, int device, radad_embed_t* out) {
+    RADAD_REQUIRE((flags & ~(RADAD_EMBED_NO_SHARED_FRAMES | RADAD_EMBED_LOGMEL_F32 | RADAD_EMBED_LOGMEL_DFT_GEMM)) == 0,
+                  "radad_embed_create_ex: unknown flag bits 0x%x", flags);
     RADAD_REQUIRE(cfg && mel_filters_host && proj_w_host && proj_b_host && out, "radad_embed_create: NULL argument");
     RADAD_REQUIRE(cfg->n_fft == N_FFT && cfg->fft_hop == FFT_HOP && cfg->n_mels == N_MELS,
                   "radad_embed_create: only n_fft=400 / hop=160 / 80 mels (the HF Whisper front-end) is built");
@@ -1447,20 +1454,21 @@ int radad_embed_create(const radad_embed_cfg* cfg, const float* mel_filters_host
             if (mel_filters_host[0 * N_MELS + mel] != 0.f) ok = false;               // bin 0 must carry no weight
             if (mel >= 2 && mel_filters_host[1 * N_MELS + mel] != 0.f) ok = false;    // bin 1 only in bands 0 and 1
         }
-        const char* e = radad_env_override("RADAD_LOGMEL_SHARED", "0 keeps one log-mel transform per (segment, frame) even where overlapping segments share frames (k_logmel_h instead of k_logmel_h_clip), for extractors created from now on");
-        if (e && atoi(e) == 0) ok = false;
+        // (flags choose; the environment names are announced overrides for experiments only)
+        const char* e = radad_env_override("RADAD_LOGMEL_SHARED", "0 keeps one log-mel transform per (segment, frame) even where overlapping segments share frames (k_logmel_h instead of the clip kernels), for extractors created from now on");
+        if ((e && atoi(e) == 0) || (flags & RADAD_EMBED_NO_SHARED_FRAMES)) ok = false;
         h->share_frames = ok ? 1 : 0;
         h->share_H = ok ? hopf : 0;
         h->fb1[0] = mel_filters_host[1 * N_MELS + 0];
         h->fb1[1] = mel_filters_host[1 * N_MELS + 1];
     }
-    { const char* e = radad_env_override("RADAD_LOGMEL_F32", "non-zero selects the fp32-MFMA log-mel kernel (k_logmel, ~2x slower) for extractors created from now on"); h->logmel_f32 = (e && atoi(e) != 0) ? 1 : 0; }
+    { const char* e = radad_env_override("RADAD_LOGMEL_F32", "non-zero selects the fp32-MFMA log-mel kernel (k_logmel, ~2x slower) for extractors created from now on"); h->logmel_f32 = ((e && atoi(e) != 0) || (flags & RADAD_EMBED_LOGMEL_F32)) ? 1 : 0; }
     std::vector<float> fft_tab(FC_TAB_FLOATS);
     {
         // the shared-frame work list as a radix FFT on the vector ALU whenever the configuration allows sharing and the filter bank is triangular
         bool ok = h->share_frames && !h->logmel_f32 && fc_build_tables(mel_filters_host, fft_tab.data(), &h->fft_adv2);
         const char* e = radad_env_override("RADAD_LOGMEL_FFT", "0 keeps the DFT-as-GEMM log-mel kernel (k_logmel_h_clip) instead of the radix FFT (k_logmel_fft_clip) for extractors created from now on");
-        if (e && atoi(e) == 0) ok = false;
+        if ((e && atoi(e) == 0) || (flags & RADAD_EMBED_LOGMEL_DFT_GEMM)) ok = false;
         h->logmel_fft = ok ? 1 : 0;
     }
     int rc = put(&h->basis, basis.data(), basis.size() * sizeof(float));

@@ -2011,7 +2011,11 @@ struct radad_knn_s {
     _Float16* hi = nullptr;      // [hi_cap][dim]
     float* rscale = nullptr;     // [hi_cap] 2^-e per row (nullptr for cosine stores: one scale, 2^-14)
     int64_t hi_rows = 0, hi_cap = 0;
-    int hi_off = 0;              // 1: disabled (RADAD_KNN_HI=0, or its allocation failed)
+    int hi_off = 0;              // 1: disabled (RADAD_KNN_OPT_HI_PLANE 0 / RADAD_KNN_HI=0, or its allocation failed)
+    // kernel choices of this handle (radad_knn_set_option; the environment names are announced overrides of the defaults set at creation)
+    int opt_centre = -1;         // -1: decided per store from |mean|^2 / mean |y|^2; 0 never, 1 always
+    int opt_smallq_hi = 1;       // small batches stream the f16 plane (0: the fp32 rows)
+    int opt_wide_min_q = 17;     // smallest batch that takes the 256-query tile scan
     unsigned* stat = nullptr;    // device [3] float bits: max |y'|, max |y' - yh| (y' = y - mu when the plane is centred, else y) and
                                  // max |y| over rows [0, stat_rows)
     int64_t stat_rows = 0;
@@ -2176,7 +2180,7 @@ constexpr float KM_CENTRE_FRACTION = 0.02f;
 static bool knn_choose_centre(radad_knn_t h, hipStream_t st) {
     const int64_t m = std::min<int64_t>(h->ntotal, KM_MAX_ROWS);
     if (m < 64 || h->f16) return false;
-    static const int centre_env = [] { const char* e = radad_env_override("RADAD_KNN_CENTRE", "0 never centres the f16 plane, 1 always does (default: decided per store from |mean|^2 / mean |y|^2)"); return e ? atoi(e) : -1; }();
+    const int centre_env = h->opt_centre;
     if (centre_env == 0) return false;
     const int ncb = (h->dim + 255) / 256;
     float *part = nullptr, *mu = nullptr, *out2 = nullptr;
@@ -2310,7 +2314,12 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
     if (!h) { radad_set_error("out of host memory"); return RADAD_ENOMEM; }
     h->dim = dim; h->metric = metric; h->device = device; h->id_base = id_base; h->f16 = store_dtype == RADAD_STORE_F16;
     // RADAD_KNN_HI=0 keeps every search on the fp32 kernels (bench.py --scan f32); read once, at creation
+    // defaults of the handle's options (radad_knn_set_option changes them); an environment variable of the old name overrides the
+    // default for handles created from now on, announced once on stderr -- for experiments only
     { const char* e = radad_env_override("RADAD_KNN_HI", "0 keeps every search of stores created from now on off the certified f16 scan (fp32 kernels: ~8x slower scans)"); h->hi_off = (e && atoi(e) == 0) ? 1 : 0; }
+    { const char* e = radad_env_override("RADAD_KNN_CENTRE", "0 never centres the f16 plane, 1 always does (default: decided per store from |mean|^2 / mean |y|^2)"); h->opt_centre = e ? atoi(e) : -1; }
+    { const char* e = radad_env_override("RADAD_KNN_SMALLQ_HI", "0 makes small batches stream the fp32 rows instead of the f16 plane (twice the bytes)"); h->opt_smallq_hi = e ? atoi(e) : 1; }
+    { const char* e = radad_env_override("RADAD_WIDE_MIN_Q", "smallest batch that takes the 256-query tile scan (default 17)"); h->opt_wide_min_q = e ? atoi(e) : SQ_NQ + 1; }
     {
         DeviceGuard g(device);
         if (hipHostMalloc(reinterpret_cast<void**>(&h->host_count), 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
@@ -2361,6 +2370,34 @@ int radad_knn_destroy(radad_knn_t h) {
 int radad_knn_dim(radad_knn_t h, int* dim) { RADAD_REQUIRE(h && dim, "NULL argument"); *dim = h->dim; return RADAD_OK; }
 int radad_knn_metric(radad_knn_t h, int* metric) { RADAD_REQUIRE(h && metric, "NULL argument"); *metric = h->metric; return RADAD_OK; }
 int radad_knn_ntotal(radad_knn_t h, int64_t* n) { RADAD_REQUIRE(h && n, "NULL argument"); *n = h->ntotal; return RADAD_OK; }
+
+int radad_knn_set_option(radad_knn_t h, int option, int value) {
+    RADAD_REQUIRE(h, "NULL handle");
+    std::lock_guard<std::mutex> lk(h->mu);
+    switch (option) {
+        case RADAD_KNN_OPT_HI_PLANE:
+            RADAD_REQUIRE(value == 0 || value == 1, "radad_knn_set_option: HI_PLANE takes 0 or 1");
+            RADAD_REQUIRE(h->hi == nullptr || value == 1, "radad_knn_set_option: the f16 plane of this store is already built; switch it off before the first large-batch search");
+            h->hi_off = value ? 0 : 1;
+            return RADAD_OK;
+        case RADAD_KNN_OPT_CENTRE:
+            RADAD_REQUIRE(value >= -1 && value <= 1, "radad_knn_set_option: CENTRE takes -1 (decide per store), 0 or 1");
+            RADAD_REQUIRE(h->hi == nullptr, "radad_knn_set_option: the f16 plane of this store is already built; choose its centring before the first large-batch search");
+            h->opt_centre = value;
+            return RADAD_OK;
+        case RADAD_KNN_OPT_SMALLQ_HI:
+            RADAD_REQUIRE(value == 0 || value == 1, "radad_knn_set_option: SMALLQ_HI takes 0 or 1");
+            h->opt_smallq_hi = value;
+            return RADAD_OK;
+        case RADAD_KNN_OPT_WIDE_MIN_Q:
+            RADAD_REQUIRE(value >= 1, "radad_knn_set_option: WIDE_MIN_Q must be >= 1");
+            h->opt_wide_min_q = value;
+            return RADAD_OK;
+        default:
+            radad_set_error("radad_knn_set_option: unknown option %d", option);
+            return RADAD_EINVAL;
+    }
+}
 
 int radad_knn_reserve(radad_knn_t h, int64_t capacity) {
     RADAD_REQUIRE(h, "NULL handle");
@@ -2538,7 +2575,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     int n_qtiles, n_splits;
     int64_t chunk_rows;
     knn_geometry(std::max<int64_t>(h->ntotal, 1), nq, &n_qtiles, &n_splits, &chunk_rows);
-    static const int wide_min_q = [] { const char* e = radad_env_override("RADAD_WIDE_MIN_Q", "smallest batch that takes the 256-query tile scan (default 17)"); return e ? atoi(e) : SQ_NQ + 1; }();
+    const int wide_min_q = h->opt_wide_min_q;
     bool use_hi = false, skipped_hi = false;
     int s_splits = 0;
     const int ksel = k + margin;                 // list length of the fp32 tile kernels
@@ -2575,7 +2612,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     if (!use_hi && cert && !knn_ensure_hi(h, st, false)) { radad_set_error("store statistics could not be computed"); return RADAD_EHIP; }
     const bool smallq_geom = !use_hi && nq <= SQ_NQ && ksel <= 32 && h->ntotal > 0;
     // the small batch over the f16 plane (certified like the tile scan): stores the plane is kept for, or fp16 stores
-    static const int smallq_hi_on = [] { const char* e = radad_env_override("RADAD_KNN_SMALLQ_HI", "0 makes small batches stream the fp32 rows instead of the f16 plane (twice the bytes)"); return e ? atoi(e) : 1; }();
+    const int smallq_hi_on = h->opt_smallq_hi;
     bool smallq_hi = false;
     if (smallq_geom && cert && smallq_hi_on && h->dim % 64 == 0 && h->ntotal >= 16384 && !h->hi_off && !skipped_hi &&
         sq_lds_hi <= SQ_LDS_BUDGET) {

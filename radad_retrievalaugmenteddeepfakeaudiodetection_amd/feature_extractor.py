@@ -95,9 +95,19 @@ class MelProjectionFeatureExtractor:
             cfg.levels[i] = int(l)
         cfg.pool_mode = _lib.POOL_MAX if mode == "max" else _lib.POOL_AVG
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        # which log-mel kernel (all within the parity bar; A/B measurements and the parity tests choose through these knobs, read the
+        # way the reference reads its optional ones): melproj_share_frames (default True), melproj_logmel_f32 (False),
+        # melproj_logmel_fft (True: the radix FFT on the vector ALU; False: the DFT-as-GEMM on the matrix pipe)
+        flags = 0
+        if not getattr(config, "melproj_share_frames", True):
+            flags |= _lib.EMBED_NO_SHARED_FRAMES
+        if getattr(config, "melproj_logmel_f32", False):
+            flags |= _lib.EMBED_LOGMEL_F32
+        if not getattr(config, "melproj_logmel_fft", True):
+            flags |= _lib.EMBED_LOGMEL_DFT_GEMM
         h = C.c_void_p()
-        _lib.check(lib.radad_embed_create(C.byref(cfg), self.mel_filters.ctypes.data, w.ctypes.data, b.ctypes.data,
-                                          self._dev_index, C.byref(h)), "radad_embed_create")
+        _lib.check(lib.radad_embed_create_ex(C.byref(cfg), flags, self.mel_filters.ctypes.data, w.ctypes.data, b.ctypes.data,
+                                             self._dev_index, C.byref(h)), "radad_embed_create")
         self._h = h
         self._lib = lib
         d, t = C.c_int(), C.c_int()

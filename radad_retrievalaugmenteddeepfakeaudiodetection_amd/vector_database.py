@@ -72,12 +72,23 @@ def write_faiss_flat(path: str, rows: np.ndarray, metric: str):
         rows.tofile(f)
 
 
+def knn_options_from_config(config):
+    """the optional scan knobs, read the way the reference reads its own optional ones (getattr with a default,
+    vector_database.py:43,67,80): knn_hi_plane, knn_centre, knn_smallq_hi, knn_wide_min_q; absent / None = the library's default"""
+    opts = dict(hi_plane=getattr(config, "knn_hi_plane", None), centre=getattr(config, "knn_centre", None),
+                smallq_hi=getattr(config, "knn_smallq_hi", None), wide_min_q=getattr(config, "knn_wide_min_q", None))
+    return {k: v for k, v in opts.items() if v is not None}
+
+
 class HipFlatIndex:
     """Flat (exhaustive) index living in HBM.  Mirrors the slice of faiss.IndexFlat{L2,IP} the reference uses."""
 
     is_trained = True   # flat indexes need no training (vector_database.py:124)
 
-    def __init__(self, d: int, metric: int, device: int = 0, id_base: int = 0, store_f16: bool = False):
+    def __init__(self, d: int, metric: int, device: int = 0, id_base: int = 0, store_f16: bool = False, hi_plane=None, centre=None,
+                 smallq_hi=None, wide_min_q=None):
+        """hi_plane / centre / smallq_hi / wide_min_q: kernel choices of the handle (radad_knn_set_option; None = the library's
+        default).  They change speed, never results: A/B measurements and the parity tests select kernels through them."""
         self._lib = _lib.load()
         self.d = int(d)
         self.metric = int(metric)
@@ -88,6 +99,11 @@ class HipFlatIndex:
         _lib.check(self._lib.radad_knn_create_ex(self.d, self.metric, _lib.STORE_F16 if self.store_f16 else _lib.STORE_F32,
                                                  self.device, self.id_base, C.byref(h)), "radad_knn_create")
         self._h = h
+        self.options = dict(hi_plane=hi_plane, centre=centre, smallq_hi=smallq_hi, wide_min_q=wide_min_q)
+        for opt, val in ((_lib.KNN_OPT_HI_PLANE, hi_plane), (_lib.KNN_OPT_CENTRE, centre), (_lib.KNN_OPT_SMALLQ_HI, smallq_hi),
+                         (_lib.KNN_OPT_WIDE_MIN_Q, wide_min_q)):
+            if val is not None:
+                _lib.check(self._lib.radad_knn_set_option(self._h, opt, int(val)), "radad_knn_set_option")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -489,7 +505,8 @@ class VectorDatabase:
         else:
             raise ValueError(f"Unsupported index type: {index_type}")
         self.index = HipFlatIndex(dimension, metric, self.device_id, id_base,
-                                  store_f16=bool(getattr(self.config, "use_float16", False)))          # vector_database.py:80
+                                  store_f16=bool(getattr(self.config, "use_float16", False)),
+                                  **knn_options_from_config(self.config))          # vector_database.py:80
         logging.info(f"Created HIP flat index on device {self.device_id} dim={dimension} type={index_type}")
 
     # vector_database.py:108-151
@@ -689,7 +706,7 @@ class VectorDatabase:
                     raise ValueError("sharded load needs a flat store")
                 lo, hi = shard_bounds(HipFlatIndex.snapshot_info(self.db_path)["ntotal"], world, rank)
                 self.index = HipFlatIndex(self.index.d, self.index.metric, device=self.device_id, id_base=lo,
-                                          store_f16=self.index.store_f16)
+                                          store_f16=self.index.store_f16, **{k: v for k, v in getattr(self.index, "options", {}).items() if v is not None})
                 self.index.load(self.db_path, lo, hi - lo)
                 self.vector_paths, self.vector_labels = self.vector_paths[lo:hi], self.vector_labels[lo:hi]
                 if isinstance(self.vector_metadata, dict):

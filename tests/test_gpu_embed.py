@@ -111,20 +111,23 @@ def test_projection_column_scales(gpu, g_fe, tmp_path):
     np.testing.assert_allclose(feats[:, 5], b[5], rtol=0, atol=0)
 
 
-def test_fp32_kernels_behind_env_flags(gpu, monkeypatch):
-    """RADAD_LOGMEL_F32=1 selects the fp32-MFMA log-mel kernel; both builds of the front-end agree to the parity bar"""
+def test_log_mel_kernels_agree(gpu):
+    """the four log-mel kernels -- radix FFT on the vector ALU (default), DFT-as-GEMM on the f16 matrix pipe with and without
+    shared frames, folded DFT on the fp32 matrix pipe -- chosen through the extractor's knobs (radad_embed_create_ex flags): all
+    within the parity bar of the float64 oracle and of each other"""
     import torch
     wav = synth.audio(0, 4, 64000, 77)
     offs = np.arange(5) * 64000
-    out = []
-    for flag in ("0", "1"):
-        monkeypatch.setenv("RADAD_LOGMEL_F32", flag)
-        fe, _ = _fe(gpu, feature_dim=128, tpp_levels=[1, 2])
+    out, kinds = [], []
+    for kw in (dict(), dict(melproj_logmel_fft=False), dict(melproj_share_frames=False), dict(melproj_logmel_f32=True)):
+        fe, _ = _fe(gpu, feature_dim=128, tpp_levels=[1, 2], **kw)
         out.append(fe.embed_clips(torch.from_numpy(wav.reshape(-1)).to(gpu), offs).cpu().numpy())
-    np.testing.assert_allclose(out[0], out[1], rtol=0, atol=5e-5)
+        kinds.append(fe.last_logmel_kind())
+    assert kinds == ["clip_frames_fft", "clip_frames", "per_segment", "per_segment"]
     ref = O.embed_clips(list(wav), 32000, 16000, fe.proj_w, fe.proj_b, (1, 2), "max")
-    np.testing.assert_allclose(out[0], ref, rtol=0, atol=1e-4)
-    np.testing.assert_allclose(out[1], ref, rtol=0, atol=1e-4)
+    for o in out:
+        np.testing.assert_allclose(o, ref, rtol=0, atol=1e-4)
+        np.testing.assert_allclose(o, out[0], rtol=0, atol=5e-5)
 
 
 def test_tpp_matches_reference_golden(gpu, golden_dir):

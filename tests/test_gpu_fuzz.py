@@ -165,9 +165,11 @@ def test_fuzz_scan_phases_and_planes(gpu, knn_oracle_lib, seed):
         del idx, rows, stored
 
 
+@pytest.mark.parametrize("kernel", ["fft", "gemm"])
 @pytest.mark.parametrize("seed", [21, 22])
-def test_fuzz_embed_shared_frames(gpu, seed):
-    """the shared-frame log-mel kernel (k_logmel_h_clip) under random segment shapes: T = 8 .. 200 frames per segment, segment hops
+def test_fuzz_embed_shared_frames(gpu, seed, kernel):
+    """the shared-frame log-mel kernels (k_logmel_fft_clip: radix FFT on the vector ALU; k_logmel_h_clip: DFT-as-GEMM on the matrix
+    pipe) under random segment shapes: T = 8 .. 200 frames per segment, segment hops
     of 2 .. 150 frames with one to four owners per frame, clips from shorter than a segment (zero padded) to dozens of segments
     (edge-only chunks), all pooling options; against the numpy float64 oracle, host- and device-resident offsets bit for bit."""
     import torch
@@ -184,7 +186,7 @@ def test_fuzz_embed_shared_frames(gpu, seed):
         cfg = R.Config()
         cfg.update(device=gpu, feature_dim=F, tpp_levels=levels, tpp_pooling_type=mode, segment_length=L / 16000,
                    segment_overlap=1.0 - (hop + 0.25) / L,               # (the mirror takes int(L (1 - overlap)) like the reference)
-                   melproj_normalize=norm, melproj_seed=300 + 10 * seed + case)
+                   melproj_normalize=norm, melproj_seed=300 + 10 * seed + case, melproj_logmel_fft=(kernel == "fft"))
         fe = R.MelProjectionFeatureExtractor(cfg)
         assert (fe.segment_length, fe.hop_length) == (L, hop), (T, H, fe.segment_length, fe.hop_length)
         nclip = int(rng.integers(1, 5))
@@ -202,7 +204,7 @@ def test_fuzz_embed_shared_frames(gpu, seed):
         wave = torch.from_numpy(np.concatenate(clips)).to(gpu)
         emb = fe.embed_clips(wave, offs)
         what = dict(seed=seed, case=case, T=T, H=H, F=F, levels=levels, mode=mode, norm=norm, lens=lens)
-        assert fe.last_logmel_kind().startswith("clip_frames"), what
+        assert fe.last_logmel_kind() == ("clip_frames_fft" if kernel == "fft" else "clip_frames"), what
         emb_dev = fe.embed_clips(wave, torch.from_numpy(offs).to(gpu))
         ref = O.embed_clips(clips, L, hop, fe.proj_w, fe.proj_b, tuple(levels), mode, normalize=norm)
         err = float(np.abs(emb.cpu().numpy() - ref).max())

@@ -12,10 +12,10 @@ from oracle import synth
 pytestmark = pytest.mark.gpu
 
 
-def _mk(gpu, metric, dim, id_base=0):
+def _mk(gpu, metric, dim, id_base=0, **options):
     from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
     m = {"L2": _lib.METRIC_L2, "IP": _lib.METRIC_IP, "COSINE": _lib.METRIC_COSINE}[metric]
-    return HipFlatIndex(dim, m, gpu.index or 0, id_base)
+    return HipFlatIndex(dim, m, gpu.index or 0, id_base, **options)
 
 
 def _check(D, I, od, oi, metric, unit):
@@ -58,12 +58,11 @@ def test_knn_matches_oracle(gpu, metric, n, nq, dim, k):
                                         (2500, 9, 96, 30),         # small batch with k too large for the streaming kernel
                                         (5000, 16, 2048, 10),      # streaming kernel at its largest dim
                                         (5000, 3, 4096, 10)])      # small batch, dim beyond the streaming kernel
-@pytest.mark.parametrize("split", ["1", "0"])
-def test_knn_kernel_variants(gpu, monkeypatch, split, metric, n, nq, dim, k):
+@pytest.mark.parametrize("split", [1, 0])
+def test_knn_kernel_variants(gpu, split, metric, n, nq, dim, k):
     """dispatch branches of radad_knn_search on small stores: fp32 tile kernel with register lists (16/32), generic tile
-    kernel, streaming small-batch kernel -- each followed by the certified float64 re-rank (RADAD_KNN_HI only matters for
+    kernel, streaming small-batch kernel -- each followed by the certified float64 re-rank (the hi_plane option only matters for
     stores of >= 16384 rows: test_knn_wide_kernel)"""
-    monkeypatch.setenv("RADAD_KNN_HI", split)
     db = synth.rows(0, n, dim, 1001)
     q = synth.rows(0, nq, dim, 1002)
     for j in range(nq):
@@ -120,17 +119,16 @@ def test_knn_wide_kernel(gpu, metric, n, nq, dim, k, f16):
         assert idx.last_launch()["block_threads"] == (512 if n >= 33000 else 256)
 
 
-def test_knn_wide_kernel_equals_fp32_tile_kernel(gpu, monkeypatch):
-    """RADAD_KNN_HI=0 keeps an fp32 store on the fp32 tile kernel; both paths return identical ids and distances
-    (the float64 re-rank decides both)."""
+def test_knn_wide_kernel_equals_fp32_tile_kernel(gpu):
+    """hi_plane=0 (radad_knn_set_option) keeps an fp32 store on the fp32 tile kernel; both paths return identical ids and
+    distances (the float64 re-rank decides both)."""
     from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
     n, nq, dim, k = 20000, 400, 256, 10
     db = synth.rows(0, n, dim, 2101)
     q = synth.rows(0, nq, dim, 2102)
     res = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("RADAD_KNN_HI", flag)
-        idx = HipFlatIndex(dim, _lib.METRIC_L2, 0, 0)
+    for flag in (1, 0):
+        idx = HipFlatIndex(dim, _lib.METRIC_L2, 0, 0, hi_plane=flag)
         idx.add(db)
         res.append(idx.search(q, k) + (idx.last_launch()["block_threads"],))
     assert (res[0][2], res[1][2]) == (512, 256)
@@ -515,9 +513,9 @@ def test_knn_truncated_lists_recheck(gpu, metric):
 
 @pytest.mark.parametrize("metric", ["L2", "IP", "COSINE"])
 @pytest.mark.parametrize("f16", [False, True])
-def test_small_batch_on_the_f16_plane(gpu, monkeypatch, metric, f16):
+def test_small_batch_on_the_f16_plane(gpu, metric, f16):
     """<= 16 queries on a store of >= 16384 rows stream the f16 plane (k_knn_hi_smallq) and are certified like the tile scan; the
-    same store with the plane switched off (RADAD_KNN_HI=0 at creation) streams the fp32 rows: both are the float64 brute force."""
+    same store with the plane switched off (hi_plane=0 at creation) streams the fp32 rows: both are the float64 brute force."""
     from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
     m = {"L2": _lib.METRIC_L2, "IP": _lib.METRIC_IP, "COSINE": _lib.METRIC_COSINE}[metric]
     n, dim, k = 40000, 128, 15
@@ -527,9 +525,7 @@ def test_small_batch_on_the_f16_plane(gpu, monkeypatch, metric, f16):
         db[(j * 2003 + 9) % n] = q[j] + np.float32(0.03) * synth.rows(j, 1, dim, 8803)[0]
     idx = HipFlatIndex(dim, m, 0, store_f16=f16)
     idx.add(db)
-    monkeypatch.setenv("RADAD_KNN_HI", "0")
-    ref = HipFlatIndex(dim, m, 0, store_f16=f16)
-    monkeypatch.delenv("RADAD_KNN_HI")
+    ref = HipFlatIndex(dim, m, 0, store_f16=f16, hi_plane=0)
     ref.add(db)
     for nq in (1, 5, 16):
         D, I = idx.search(q[:nq], k)
