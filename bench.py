@@ -102,6 +102,9 @@ def main():
                          "only its own clips: no collective at all (any BASELINE store fits one 288 GB GPU)")
     ap.add_argument("--mode", choices=["step", "predict"], default="step")
     ap.add_argument("--predict-queries", type=int, default=1)
+    ap.add_argument("--end-to-end", action="store_true", help="--mode predict: time HotPathPipeline.predict (pipeline.py:1038-1103) for one "
+                    "3 s clip -- load -> embed -> search(exclude_self) -> RADADModel -> sigmoid -- against a --db-rows x 3584 L2 store "
+                    "(F = 512, levels [1, 2, 4]: the reference's Whisper shape); latency per call, host work included")
     ap.add_argument("--dim", type=int, default=DIM, help="--mode predict only: embedding dimension of the store (the reference's own "
                     "stores are 5376- or 3584-dimensional: 7 pyramid bins x 768 / 512 features); != 512 uses synthetic queries")
     ap.add_argument("--metric", choices=["cosine", "l2"], default="cosine", help="--mode predict only (the reference's default index is L2)")
@@ -147,6 +150,60 @@ def main():
     from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
     from radad_retrievalaugmenteddeepfakeaudiodetection_amd.sharded import ReplicatedSearch, ShardedSearch, shard_bounds
     lib = _lib.load()
+
+    if args.mode == "predict" and args.end_to_end:
+        assert world == 1, "--mode predict is a one-GPU measurement"
+        cfg = R.Config()
+        cfg.update(device=dev, feature_dim=512, tpp_levels=[1, 2, 4], top_k=5, vector_db_index_type="L2",
+                   vector_db_path=os.path.join("/tmp", f"radad_bench_vdb_{os.getpid()}"))
+        pipe = R.HotPathPipeline(cfg)
+        D_ = pipe.tpp.get_output_dim()
+        n_rows = args.db_rows if args.db_rows != DB_ROWS else 25423
+        clip = torch.empty(48000, device=dev, dtype=torch.float32)
+        _lib.check(lib.radad_synth_audio(clip.data_ptr(), 0, 1, 48000, AUDIO_SEED, local_rank, _lib.stream_ptr(dev)))
+        clip_h = clip.cpu().numpy()
+
+        class _DS:
+            def load_audio(self, path):
+                return clip_h
+        emb = pipe.process_audio_batch(["/eval/q.wav"], _DS())
+        rows = torch.empty((n_rows, D_), device=dev, dtype=torch.float32)
+        _lib.check(lib.radad_synth_rows(rows.data_ptr(), 0, n_rows, D_, DB_SEED, local_rank, _lib.stream_ptr(dev)))
+        rows = rows * (0.05 * emb.abs().mean()) + emb.mean()
+        rows[17] = emb[0] + 0.01 * rows[18]
+        pipe.vector_db.add_vectors(rows, [f"/train/f{i}.wav" for i in range(n_rows)], [float(i % 2) for i in range(n_rows)],
+                                   {"speaker_id": ["s"] * n_rows})
+        model = R.RADADModel(cfg, D_).eval().to(dev)
+        for _ in range(max(3, args.warmup)):
+            out_p = pipe.predict("/eval/q.wav", _DS(), model)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(args.steps):
+            t0 = time.perf_counter()
+            out_p = pipe.predict("/eval/q.wav", _DS(), model)
+            lat.append(1e3 * (time.perf_counter() - t0))
+        # the device part alone: the same calls queued without reading anything back
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            e_ = pipe.process_audio_batch(["/eval/q.wav"], _DS())
+            v_, l_ = pipe.retrieve_similar_vectors(e_, query_paths=["/eval/q.wav"], exclude_self=True)
+            lg_ = model(v_, e_)
+        torch.cuda.synchronize()
+        dev_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+        lat = np.asarray(lat)
+        print(json.dumps({"metric": f"predict() latency, one 3 s clip @{n_rows}x{D_} L2 store (pipeline.py:1038-1103)",
+                          "value": round(float(np.median(lat)), 4), "unit": "ms", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(float(lat.mean()), 4), "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"HotPathPipeline.predict: load -> embed (F=512, levels [1,2,4]) -> L2 top-15 with the "
+                                                 f"clip's basename excluded -> RADADModel -> sigmoid; {n_rows} x {D_} store", "db_rows": n_rows,
+                                     "dim": D_, "k_search": 15},
+                          "latency_ms": {"median": round(float(np.median(lat)), 4), "p90": round(float(np.percentile(lat, 90)), 4),
+                                         "min": round(float(lat.min()), 4)},
+                          "queued_without_readback_ms": round(dev_ms, 4),
+                          "result": {k: out_p[k] for k in ("prediction", "probability_spoof", "retrieved_files")},
+                          "scan_kind": pipe.vector_db.index.last_launch()["scan_kind"]}), flush=True)
+        return
 
     if args.mode == "predict" and (args.dim != DIM or args.metric != "cosine" or args.k != TOP_K):
         # ---- the online search at the reference's own shape (pipeline.py:1038-1054: ONE query, D = 5376 / 3584, k = 15, L2 by

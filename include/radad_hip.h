@@ -178,6 +178,13 @@ int radad_knn_last_scan_launches(radad_knn_t h, int* n_launches);
  * of the rows is subtracted before rounding (stores of embeddings that share most of their mean); one_scale = one power-of-two
  * scale for all rows (rows of one magnitude: the scan applies no per-score arithmetic) */
 int radad_knn_plane_info(radad_knn_t h, int* built, int* centred, int* one_scale);
+/* How often the plane of this store was RE-decided (dropped and rebuilt with a new centre and scale): it is decided from the rows the
+ * store holds when it is first built; it is decided again -- 0.84 ms per million rows, one synchronisation, inside the first
+ * large-batch search that notices -- when the store has doubled since, when appended rows measure 8x beyond what the decision saw
+ * (largest element or rounding residual), or when a batch was mostly rejected by the certificate and rows were appended since
+ * (vector_database.py:134-138 appends 10 000 rows at a time; a store that drifts keeps the certified scan instead of the 8x slower
+ * fp32 fallback).  Results never depend on it. */
+int radad_knn_plane_rebuilds(radad_knn_t h, int* n_out);
 /* Certificate of the most recent search (see radad_knn_search_f64): number of queries the float64 re-rank could NOT certify
  * and that were therefore searched again by the exact float64 kernel (results are exact either way).  Synchronises with
  * that search.  radad_knn_last_certificate additionally returns the batch size and stats6 = {rejected queries, sum over

@@ -74,6 +74,7 @@ SIGNATURES = {
     "radad_knn_search_abort": (C.c_int, [C.c_void_p]),
     "radad_knn_last_scan_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_plane_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "radad_knn_plane_rebuilds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_kth_largest": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "radad_knn_last_scan_kind": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_search_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),

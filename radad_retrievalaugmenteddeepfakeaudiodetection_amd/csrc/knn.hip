@@ -2043,6 +2043,19 @@ struct radad_knn_s {
     int64_t count_nq[2] = {0, 0};    // batch size of the search a slot belongs to
     uint64_t search_seq = 0;     // certified searches so far
     int hi_skip = 0;             // searches left on the fp32 kernels after the certified scan rejected too many queries
+    // Re-deciding the plane (its centre mu and its scale are decided from the rows the store holds WHEN IT IS BUILT; add_vectors_batch
+    // appends 10 000 rows at a time, vector_database.py:134-138): it is dropped and rebuilt -- 0.84 ms per million rows, one
+    // synchronisation -- when the store has doubled since the decision, when rows appended since then measure 8x beyond what the
+    // decision saw (max |y'| or the rounding residual: the f16 scale has 8x headroom), or when a batch was mostly rejected and rows
+    // have been appended since (otherwise the same plane would come back: the fp32 fallback stays the remedy)
+    int64_t plane_decided_rows = 0;
+    float plane_stat[2] = {0.f, 0.f};     // max |y'|, max |y' - yh| right after the plane was built
+    bool replan = false;
+    int plane_rebuilds = 0;      // (radad_knn_plane_info: how often the plane was re-decided)
+    uint64_t tuned_at = 0;       // search_seq at the last change of the plane / of cap_boost: reports of EARLIER searches are not acted on
+    int cap_boost = 1;           // candidate buffers of the tile scan are 1024 entries per query x this (1 or 4): raised once when a batch
+                                 // was mostly rejected (a store of several clusters has a large |y - mu|, hence a large eps: more rows
+                                 // pass the floor than 1024) -- before the handle resorts to the fp32 kernels
     size_t esize() const { return f16 ? 2 : 4; }
     size_t row_bytes() const { return (size_t)dim * esize(); }
     // search workspace (grown on demand, reused)
@@ -2107,13 +2120,13 @@ static int knn_workspace(radad_knn_t h, size_t bytes) {
 // column means of the first `m` rows, deterministic: KM_SLICES partial sums per column in fixed order, then one block adds them
 // up, and measures |mu|^2 against the rows' mean |y|^2 (out2[0], out2[1]) for the host's decision
 constexpr int KM_SLICES = 64;
-__global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ rows, int64_t m, int dim, float* __restrict__ part /*[KM_SLICES][dim + 1]*/) {
+__global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ rows, int64_t m, int64_t row_stride, int dim, float* __restrict__ part /*[KM_SLICES][dim + 1]*/) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int64_t per = (m + KM_SLICES - 1) / KM_SLICES;
     const int64_t r0 = (int64_t)blockIdx.y * per, r1 = min(r0 + per, m);
     float s = 0.f, ss = 0.f;
     if (c < dim)
-        for (int64_t r = r0; r < r1; ++r) { const float v = rows[r * dim + c]; s += v; ss = fmaf(v, v, ss); }
+        for (int64_t r = r0; r < r1; ++r) { const float v = rows[r * row_stride * dim + c]; s += v; ss = fmaf(v, v, ss); }      // (sample row r = store row r x stride)
     if (c < dim) part[(int64_t)blockIdx.y * (dim + 1) + c] = s;
     // sum of squares of this block's columns and rows -> one value per (slice, column block), added up by k_col_final
     __shared__ float red[256];
@@ -2147,13 +2160,13 @@ __global__ __launch_bounds__(256) void k_col_final(const float* __restrict__ par
 }
 
 // max |x - mu| over the elements of the first m rows (non-negative floats order like their bit patterns)
-__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ rows, const float* __restrict__ mu, int64_t m, int dim,
+__global__ __launch_bounds__(256) void k_absmax(const float* __restrict__ rows, const float* __restrict__ mu, int64_t m, int64_t row_stride, int dim,
                                                 unsigned* __restrict__ out /*[2]: max, and min over rows of the row maximum*/) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= m) return;
     float mx = 0.f;
-    for (int i = lane; i < dim; i += 64) mx = fmaxf(mx, fabsf(rows[row * dim + i] - (mu ? mu[i] : 0.f)));
+    for (int i = lane; i < dim; i += 64) mx = fmaxf(mx, fabsf(rows[row * row_stride * dim + i] - (mu ? mu[i] : 0.f)));
     mx = wave_max(mx);
     if (lane == 0) {        // (atomics only when the row moves an extreme it can see: same-address atomics serialise)
         const unsigned u = __float_as_uint(mx);
@@ -2189,7 +2202,8 @@ static bool knn_choose_centre(radad_knn_t h, hipStream_t st) {
               hipMalloc(&out2, 2 * sizeof(float)) == hipSuccess;
     float host2[2] = {0.f, 1.f};
     if (ok) {
-        hipLaunchKernelGGL(k_col_partial, dim3(ncb, KM_SLICES), dim3(256), 0, st, (const float*)h->rows, m, h->dim, part);
+        // (the sample is spread over the WHOLE store: its first rows alone say nothing about rows appended later)
+        hipLaunchKernelGGL(k_col_partial, dim3(ncb, KM_SLICES), dim3(256), 0, st, (const float*)h->rows, m, std::max<int64_t>(1, h->ntotal / m), h->dim, part);
         hipLaunchKernelGGL(k_col_final, dim3(1), dim3(256), 0, st, (const float*)part, m, h->dim, ncb, mu, out2);
         ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(host2, out2, sizeof(host2), hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipStreamSynchronize(st) == hipSuccess;
@@ -2213,7 +2227,16 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
         h->stat_rows = 0;
     }
     const bool plane = want_plane && !h->hi_off && !h->f16 && h->dim % 64 == 0;
-    if (plane && (h->hi_cap != h->capacity || !h->hi)) {
+    if (plane && h->hi && h->hi_cap == h->capacity && h->ntotal > h->plane_decided_rows &&
+        (h->replan || h->ntotal >= 2 * h->plane_decided_rows)) {
+        (void)hipDeviceSynchronize();
+        knn_drop_plane(h);
+        ++h->plane_rebuilds;
+        h->tuned_at = h->search_seq;
+    }
+    if (plane) h->replan = false;
+    const bool fresh = plane && (h->hi_cap != h->capacity || !h->hi);
+    if (fresh) {
         (void)hipDeviceSynchronize();
         knn_drop_plane(h);
         const bool centred = knn_choose_centre(h, st);
@@ -2227,7 +2250,8 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
             const int64_t m = std::min<int64_t>(h->ntotal, KM_MAX_ROWS);
             if (m > 0 && hipMalloc(&mm, 2 * sizeof(unsigned)) == hipSuccess) {
                 (void)hipMemcpyAsync(mm, host, sizeof(host), hipMemcpyHostToDevice, st);
-                hipLaunchKernelGGL(k_absmax, dim3((unsigned)ceil_div64(m, 4)), dim3(256), 0, st, (const float*)h->rows, (const float*)h->cmu, m, h->dim, mm);
+                hipLaunchKernelGGL(k_absmax, dim3((unsigned)ceil_div64(m, 4)), dim3(256), 0, st, (const float*)h->rows, (const float*)h->cmu, m,
+                                   std::max<int64_t>(1, h->ntotal / m), h->dim, mm);
                 if (hipMemcpyAsync(host, mm, sizeof(host), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
                     float mx, mn;
                     memcpy(&mx, &host[0], 4); memcpy(&mn, &host[1], 4);
@@ -2276,6 +2300,17 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
         if (hipGetLastError() != hipSuccess) return false;
         h->stat_rows = h->ntotal;
         if (have_plane) h->hi_rows = h->ntotal;
+        if (have_plane) {
+            // what the plane's operands measure now (only searches that follow an append come through here: one small read-back)
+            float host[2] = {0.f, 0.f};
+            if (hipMemcpyAsync(host, h->stat, sizeof(host), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess) {
+                if (fresh) { h->plane_stat[0] = host[0]; h->plane_stat[1] = host[1]; h->plane_decided_rows = h->ntotal; }
+                else if ((h->plane_stat[0] > 0.f && host[0] > 8.f * h->plane_stat[0]) || (h->plane_stat[1] > 0.f && host[1] > 8.f * h->plane_stat[1])) {
+                    h->replan = true;                      // rows beyond what the scale was chosen for: decide again, now
+                    return knn_ensure_hi(h, st, want_plane);
+                }
+            } else (void)hipGetLastError();
+        }
     }
     return !want_plane || have_plane || h->f16;
 }
@@ -2564,7 +2599,13 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     if (cert && h->count_pending[cslot]) {
         RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count[cslot]));
         h->count_pending[cslot] = false;
-        if (h->hi_skip == 0 && h->count_nq[cslot] >= 64 && (int64_t)h->host_count[8 * cslot] * 4 > h->count_nq[cslot]) h->hi_skip = 8;
+        // (the report is that of search search_seq - 2: if the plane or the buffers were changed since, it says nothing about them)
+        if (h->hi_skip == 0 && h->count_nq[cslot] >= 64 && (int64_t)h->host_count[8 * cslot] * 4 > h->count_nq[cslot] &&
+            h->search_seq >= h->tuned_at + 2) {
+            if (h->hi && h->ntotal > h->plane_decided_rows) { h->replan = true; h->tuned_at = h->search_seq; }      // the store has changed since the plane was decided: decide again
+            else if (h->cap_boost == 1) { h->cap_boost = 4; h->tuned_at = h->search_seq; }                         // first: four times the candidate buffer
+            else h->hi_skip = 8;                                                  // the same plane would come back: fp32 kernels for a while
+        }
     }
 #ifdef RADAD_DEBUG_HOOKS
     if (getenv("RADAD_DEBUG_KNN")) h->hi_skip = 0;     // timing ablations (wrong results, every query rejected): stay on the kernel under test
@@ -2657,7 +2698,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     // candidates so far give (k_kth_floor), and so on: 2 launches up to 1.2 M rows, 3 up to 9.5 M.  Each admits ~8 (k + margin) rows
     // per query; the candidate buffer holds 32 (k + margin) (>= 1024): more (stores of near-duplicates) rejects the query.
     const int64_t hi_phase0 = (int64_t)8 * s_splits * KW_M;
-    const int emit_cap = use_hi ? std::min(RF_STAGE_MAX, std::max(1024, 32 * ksel)) : 0;
+    const int emit_cap = use_hi ? std::min(RF_STAGE_MAX, std::max(1024 * h->cap_boost, 32 * ksel)) : 0;
     h->last_qtiles = n_qtiles;
     h->last_threads = use_hi ? KW_THREADS : ((smallq || smallq_hi) ? SQ_THREADS : KNN_THREADS);
     h->last_kind = use_hi ? RADAD_SCAN_HI_TILE : smallq_hi ? RADAD_SCAN_HI_SMALLQ : smallq ? RADAD_SCAN_F32_SMALLQ
@@ -2767,7 +2808,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         wp.n_qtiles = n_qtiles; wp.part_score = ps; wp.part_idx = pi;
         wp.cand_cap = emit_cap; wp.cand_cnt = cand_cnt;
         wp.thr_init = nullptr;
-        wp.ksplit = 1; wp.kacc = nullptr; wp.kflag = nullptr; wp.loose_floor = 0;
+        wp.ksplit = 1; wp.kacc = nullptr; wp.kflag = nullptr; wp.loose_floor = 0; wp.chunk_stride = 0;
         wp.debug = 0; wp.stamps = nullptr;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (make exp); never in the shipped library
         { const char* dbg = getenv("RADAD_DEBUG_KNN"); wp.debug = dbg ? atoi(dbg) : 0; }
@@ -2793,9 +2834,15 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         // It uses the head of the candidate arrays; the scan overwrites them afterwards.
         {
             KnnHiParams sp = wp;
-            sp.n = (int64_t)s_splits * KW_M; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
+            // The sample's tiles are SPREAD over the store (every (tiles / s_splits)-th one).  The first s_splits tiles, as until round 4,
+            // are a sample of the store only while its rows are in random order: on a store whose rows arrive cluster by cluster
+            // (add_vectors_batch appends 10 000 rows at a time, vector_database.py:134-138) a query of the LAST cluster got a floor
+            // from rows of the first -- so loose that every row of its own cluster passed it, the candidate buffer overflowed and the
+            // certificate rejected all 256 queries of a batch (tests/test_gpu_reference_shapes.py::test_a_store_that_drifts...).
+            sp.n = h->ntotal; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
+            sp.chunk_stride = std::max<int64_t>(1, (h->ntotal / KW_M) / s_splits) * KW_M;
             const int sq_grid = sp.n_qtiles <= 8 ? sp.n_qtiles : (sp.n_qtiles + 7) / 8 * 8;
-            sp.ksplit = knn_tile_ksplit(h, sq_grid, sp.n_splits, KW_M, sp.n, st);
+            sp.ksplit = knn_tile_ksplit(h, sq_grid, sp.n_splits, KW_M, (int64_t)s_splits * KW_M, st);
             sp.kacc = h->kacc; sp.kflag = h->kflag;
             const dim3 sg((unsigned)(sq_grid * sp.n_splits * sp.ksplit)), sb(KW_THREADS);
             if (rsc == 0) hipLaunchKernelGGL(k_knn_hi_sample<0>, sg, sb, lds, st, sp);
@@ -3213,6 +3260,13 @@ int radad_knn_plane_info(radad_knn_t h, int* built, int* centred, int* one_scale
     if (built) *built = (h->hi != nullptr && h->hi_rows > 0) ? 1 : 0;
     if (centred) *centred = h->cmu != nullptr ? 1 : 0;
     if (one_scale) *one_scale = (h->hi != nullptr && h->rscale == nullptr) ? 1 : 0;
+    return RADAD_OK;
+}
+
+int radad_knn_plane_rebuilds(radad_knn_t h, int* n_out) {
+    RADAD_REQUIRE(h && n_out, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    *n_out = h->plane_rebuilds;
     return RADAD_OK;
 }
 

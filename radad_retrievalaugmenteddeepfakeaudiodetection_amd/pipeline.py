@@ -146,3 +146,41 @@ class HotPathPipeline:
             all_paths = [[paths_db[i - index.id_base] if i >= 0 else "" for i in row] for row in chosen_t.cpu().tolist()]
         vec_tensor = index.reconstruct_batch(chosen_t)                          # [B,K,D], zeros where id == -1 (pipeline.py:512)
         return pack(vec_tensor, lbl_t, all_paths, dist_t)
+
+    # ---- the online path ------------------------------------------------------------------------------------
+    def predict(self, audio_path: str, audio_dataset, radad_model, threshold: float = 0.5):
+        """pipeline.py:1038-1103 for ONE clip: segment -> embed (:1047) -> retrieve with the clip's own basename excluded (:1049-1051)
+        -> when that leaves nothing, retrieve again WITHOUT the exclusion (:1052-1055) -> RADADModel (:1076) -> sigmoid -> the
+        reference's result dict (:1096-1103).  `audio_dataset` needs `.load_audio(path)` (the reference builds an AudioDataset
+        around librosa, :1043); `radad_model` is this build's RADADModel (inference forward, csrc/proj.hip) or any module with the
+        reference's forward(retrieved_vectors, tpp_vector).  Everything between the loaded samples and the logit stays on the GPU."""
+        import logging
+        import torch
+        index = self.vector_db.index
+        if index is None or getattr(index, "ntotal", 0) == 0:
+            logging.warning("Vector DB is empty or not loaded. Retrieval will return zero neighbors.")      # :1039-1040
+        radad_model.eval()                                                                                  # :1042
+        with torch.no_grad():
+            tpp_vec = self.process_audio_batch([audio_path], audio_dataset)                                 # [1, D]
+            vecs, lbls, npaths = self.retrieve_similar_vectors(tpp_vec, query_paths=[audio_path], exclude_self=True, return_info=True)
+            if torch.count_nonzero(vecs) == 0:                                                              # :1052
+                vecs, lbls, npaths = self.retrieve_similar_vectors(tpp_vec, query_paths=[audio_path], exclude_self=False,
+                                                                   return_info=True)
+            if vecs.ndim == 2:                                                                              # :1057-1060
+                vecs = vecs.unsqueeze(1)
+            elif vecs.ndim == 1:
+                vecs = vecs.unsqueeze(0).unsqueeze(1)
+            logits = radad_model(vecs, tpp_vec)                                                             # :1076
+            if logits.ndim == 1:
+                logits = logits.unsqueeze(-1)
+            flat = logits.detach().float().view(-1)
+            prob = torch.sigmoid(flat).mean().item()                                                        # :1082
+            pred = "spoof" if prob >= float(threshold) else "bona-fide"                                     # :1083
+            logit = flat.mean().item()
+            neigh_labels = [int(x) for x in lbls.squeeze(0).detach().cpu().tolist()] if isinstance(lbls, torch.Tensor) else \
+                (list(lbls[0]) if isinstance(lbls, list) and len(lbls) else [])                             # :1087-1090
+            neigh_paths = npaths[0] if isinstance(npaths, list) and len(npaths) else []
+            retrieved = [{"file": os.path.basename(pth) if pth else "", "path": pth, "label": lab}
+                         for lab, pth in zip(neigh_labels, neigh_paths)]
+            return {"prediction": pred, "probability_spoof": float(prob), "logit": float(logit), "retrieved_labels": neigh_labels,
+                    "retrieved_files": [r["file"] for r in retrieved], "retrieved": retrieved}

@@ -249,10 +249,11 @@ class HipFlatIndex:
         return out.reshape(*idx.shape, self.d)
 
     def plane_info(self):
-        """{"built", "centred", "one_scale"} of the f16 plane the certified scans read (radad_knn_plane_info)"""
-        b, c, o = C.c_int(), C.c_int(), C.c_int()
+        """{"built", "centred", "one_scale", "rebuilds"} of the f16 plane the certified scans read (radad_knn_plane_info, _plane_rebuilds)"""
+        b, c, o, r = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _lib.check(self._lib.radad_knn_plane_info(self._h, C.byref(b), C.byref(c), C.byref(o)))
-        return {"built": bool(b.value), "centred": bool(c.value), "one_scale": bool(o.value)}
+        _lib.check(self._lib.radad_knn_plane_rebuilds(self._h, C.byref(r)))
+        return {"built": bool(b.value), "centred": bool(c.value), "one_scale": bool(o.value), "rebuilds": r.value}
 
     def last_launch(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()

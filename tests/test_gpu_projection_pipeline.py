@@ -354,3 +354,62 @@ def test_projection_layer_extras(gpu):
         assert torch.equal(layer.memory_efficient_forward(x, chunk_size=32), full)
         assert torch.equal(layer.memory_efficient_forward(x[:8], chunk_size=32), full[:8])
     assert layer.profile_performance((4, 5, 512), num_iterations=3) > 0
+
+
+def test_predict_end_to_end_on_the_reference_store_shape(gpu, tmp_path):
+    """pipeline.py:1038-1103 chained: one clip -> embed -> retrieve(exclude_self) -> retry without the exclusion when that leaves
+    nothing (:1052-1055) -> RADADModel -> sigmoid, on the reference's Whisper-shaped store (25 423 x 3584: F = 512, levels [1, 2, 4],
+    L2, top_k = 5, k_search = 15), against the oracle composition embed_clips -> knn -> retrieve_postprocess -> radad_model_forward.
+    Both branches: a store with other files near the query (normal), and a store in which EVERY row carries the query's basename
+    (the exclusion removes all 15 hits -> the retry keeps them)."""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    cfg = R.Config()
+    cfg.update(device=gpu, feature_dim=512, tpp_levels=[1, 2, 4], top_k=5, vector_db_index_type="L2",
+               vector_db_path=str(tmp_path / "vdb"))
+    pipe = R.HotPathPipeline(cfg)
+    D = pipe.tpp.get_output_dim()
+    assert D == 3584
+    wav = synth.audio(0, 1, 48000, 4711)[0]                               # the reference's 3.0 s clip (dataset.py:143)
+    qpath = "/eval/query_clip.wav"
+    ds = _FakeDataset({qpath: wav})
+    fe = pipe.feature_extractor
+    emb_ref = O.embed_clips([wav], 32000, 16000, fe.proj_w, fe.proj_b, (1, 2, 4), "max")          # [1, 3584] float64
+    n = 25423
+    base = synth.rows(0, n, D, 97) * np.float32(0.05 * np.abs(emb_ref).mean()) + emb_ref.astype(np.float32).mean()
+    for j in range(40):                                                    # rows near the query: the neighbourhood that gets ranked
+        base[(j * 631 + 7) % n] = emb_ref[0].astype(np.float32) + np.float32(0.002 * (j + 1)) * synth.rows(j, 1, D, 98)[0]
+    model = R.RADADModel(cfg, D).eval().to(gpu)
+    sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, 77)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    for branch in ("normal", "retry"):
+        cfg.vector_db_path = str(tmp_path / ("vdb_" + branch))
+        pipe.vector_db = R.VectorDatabase(cfg)
+        paths = [(f"/train/file{i}.wav" if branch == "normal" else f"/train/dir{i}/query_clip.wav") for i in range(n)]
+        labels = [float(i % 2) for i in range(n)]
+        pipe.vector_db.add_vectors(base, paths, labels, {"speaker_id": ["s"] * n})
+        out = pipe.predict(qpath, ds, model)
+        assert pipe.vector_db.index.last_launch()["scan_kind"] in ("hi_smallq", "hi_smallq_ksplit")        # the streaming f16 kernels
+        # the oracle's composition, on the embedding the GPU produced (its own parity is test_process_audio_batch_and_retrieve's)
+        emb = pipe.process_audio_batch([qpath], ds)
+        np.testing.assert_allclose(emb.cpu().numpy(), emb_ref, rtol=0, atol=1e-4)
+        eq = emb.cpu().numpy()
+        od, oi = O.knn(base, eq, 15, "L2")
+        ov, ol, op, _ = O.retrieve_postprocess(od, oi, base, paths, labels, 5, D, query_paths=[qpath], exclude_self=True)
+        if branch == "retry":
+            assert not ov.any()                                            # every hit carried the query's basename
+            od, oi = O.knn(base, eq, 5, "L2")                              # :1053: exclude_self=False searches K, not K + 10
+            ov, ol, op, _ = O.retrieve_postprocess(od, oi, base, paths, labels, 5, D, query_paths=[qpath], exclude_self=False)
+        _, _, want = O.radad_model_forward(ov, eq, sd)
+        assert out["retrieved"] == [{"file": os.path.basename(p), "path": p, "label": int(l)} for p, l in zip(op[0], ol[0])]
+        assert out["retrieved_labels"] == [int(l) for l in ol[0]] and out["retrieved_files"] == [os.path.basename(p) for p in op[0]]
+        assert abs(out["logit"] - float(want[0])) < 1e-3 * max(1.0, abs(float(want[0])))
+        prob = 1.0 / (1.0 + np.exp(-float(want[0])))
+        assert abs(out["probability_spoof"] - prob) < 1e-4
+        assert out["prediction"] == ("spoof" if prob >= 0.5 else "bona-fide") and set(out) == {
+            "prediction", "probability_spoof", "logit", "retrieved_labels", "retrieved_files", "retrieved"}
+    # an empty store: zero neighbours, still a verdict (pipeline.py:1039-1040)
+    cfg.vector_db_path = str(tmp_path / "vdb_empty")
+    pipe.vector_db = R.VectorDatabase(cfg)
+    out = pipe.predict(qpath, ds, model)
+    assert out["retrieved_files"] == [""] * 5 and out["prediction"] in ("spoof", "bona-fide")

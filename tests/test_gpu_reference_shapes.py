@@ -116,6 +116,51 @@ def test_reference_store_shapes_take_the_certified_kernels(gpu, knn_oracle_lib, 
     assert torch.equal(I13, I256[:13])
 
 
+@pytest.mark.parametrize("reserve", [True, False])
+@pytest.mark.parametrize("metric", ["L2", "COSINE"])
+def test_a_store_that_drifts_after_the_plane_was_built(gpu, knn_oracle_lib, metric, reserve):
+    """The f16 plane's centre mu and scale are decided from the rows the store holds when it is first searched; add_vectors_batch
+    appends 10 000 rows at a time (vector_database.py:134-138).  20 k embedding-like rows, a search (the plane is built), then 20 k
+    rows around a DIFFERENT common component and 20 k rows 30x larger: ids must stay those of the float64 oracle throughout, and the
+    handle must not end on the fp32 fallback -- the plane is decided again (radad_knn_plane_rebuilds) and the search after that runs
+    the certified tile scan with <= 2 % of the queries rejected."""
+    import torch
+    from conftest import c_knn
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    dim, k, B, n1 = 1024, K_REF, 256, 20000
+    m = _lib.METRIC_L2 if metric == "L2" else _lib.METRIC_COSINE
+    base_a = _dev_rows(gpu, 0, 1, dim, 7101).abs() + 0.5
+    base_b = _dev_rows(gpu, 1, 1, dim, 7101).abs() * 2.0 + 0.1                # another encoder's mean
+    part = [base_a + 0.3 * _dev_rows(gpu, 0, n1, dim, 7102),
+            base_b + 0.3 * _dev_rows(gpu, n1, n1, dim, 7102),
+            30.0 * (base_a + 0.3 * _dev_rows(gpu, 2 * n1, n1, dim, 7102))]    # the same family, 30x the magnitude
+    idx = HipFlatIndex(dim, m, gpu.index or 0)
+    if reserve:
+        idx.reserve(3 * n1)            # no reallocation (which drops the plane anyway): the plane must be RE-decided in place
+    om = "L2" if metric == "L2" else "IP"
+    rows_all = []
+    for step, rows in enumerate(part):
+        q = rows[torch.arange(B, device=gpu) * 71 % n1] + 0.05 * _dev_rows(gpu, 0, B, dim, 7110 + step)      # queries near this part's rows
+        for lo in range(0, n1, 10000):
+            idx.add_device(rows[lo:lo + 10000].contiguous())
+        rows_all.append(rows)
+        stored = idx.reconstruct_batch(torch.arange(idx.ntotal, device=gpu)).cpu().numpy()
+        qn_h = (_rownorm(gpu, q) if metric == "COSINE" else q).cpu().numpy()
+        od, oi = c_knn(knn_oracle_lib, stored, qn_h[:48], k, om)
+        for rep in range(6):                                                   # (the rejection counters lag two searches; the handle may
+                                                                               #  first re-decide the plane, then widen its candidate buffers)
+            D, I = idx.search_device(q, k)
+            launch = idx.last_launch()
+            if O.rank_gaps(od).min() > 0:
+                np.testing.assert_array_equal(I[:48].cpu().numpy(), oi)
+        info = idx.plane_info()
+        assert launch["scan_kind"] == "hi_tile", (step, launch, info)          # not on the fp32 fallback
+        assert launch["certificate"]["rejected"] <= max(1, B // 50), (step, launch["certificate"], info)
+        assert info["built"], info
+    if reserve:
+        assert idx.plane_info()["rebuilds"] >= 1, idx.plane_info()             # 20 k -> 40 k rows doubled the store: decided again
+
+
 def _bench_like_store(gpu, emb, n_total, dim, seed=4321, noise_seed=99):
     """the store bench.py builds: synthetic rows + two near-duplicates of every query embedding"""
     import torch
