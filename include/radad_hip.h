@@ -12,6 +12,11 @@
  *   - handles are opaque.  A handle may be searched/reconstructed from several threads (host calls are serialised by a
  *     mutex, the device work of consecutive searches by an event: they share one workspace); add/load/destroy must
  *     not race with anything else.
+ *   - "without synchronising" has one exception per store: the FIRST large-batch search after the store was created, grown
+ *     past its capacity, or re-decided (radad_knn_plane_rebuilds) builds the f16 plane inside the call -- hipDeviceSynchronize,
+ *     hipMalloc of 2 bytes per element, one small read-back -- i.e. it stalls every stream of the device once (0.84 ms of
+ *     kernel time per million rows of 512).  Build-then-search callers never notice; a caller that interleaves adds and
+ *     searches on several streams should radad_knn_reserve up front and run one warm-up search after the last add.
  *
  * Each group cites the reference interface (file:line under the RADAD repository) it replaces.
  */

@@ -21,7 +21,8 @@ t0 = time.perf_counter(); idx.train(rows[:50000]); torch.cuda.synchronize(); out
 t0 = time.perf_counter(); idx.add(rows); torch.cuda.synchronize(); out["add_s"] = round(time.perf_counter() - t0, 3)
 flat = R.HipFlatIndex(D, _lib.METRIC_L2, 0); flat.add_device(rows)
 idx.nprobe = NPROBE
-for nq in (1, 256, 1024):
+NQS = tuple(int(x) for x in sys.argv[1].split(",")) if len(sys.argv) > 1 else (1, 256, 1024)
+for nq in NQS:
     q = rows[(torch.arange(nq, device=dev) * 977 + 5) % N] + 0.5 * torch.randn((nq, D), device=dev)
     for _ in range(2):
         Di, Ii = idx.search_device(q, K)
