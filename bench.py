@@ -223,7 +223,7 @@ def main():
         for _ in range(args.warmup):
             index.search_device(qp, k)
         torch.cuda.synchronize()
-        index.profile(True)
+        index.profile(True, every=4)      # (an event pair holds the dependent kernels back ~12 us: every 4th search carries one)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             D, I = index.search_device(qp, k)
@@ -349,7 +349,7 @@ def main():
         for _ in range(args.warmup):
             vdb.index.search_device(qp, TOP_K)
         barrier()
-        vdb.index.profile(True)
+        vdb.index.profile(True, every=4)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             D, I = vdb.index.search_device(qp, TOP_K)
@@ -388,10 +388,11 @@ def main():
         step()
     barrier()
     step_no[0] = 0
-    # HIP events on the launch stream bracket every launch of the DOMINANT kernel (the scan) throughout the timed region.  The two
-    # embedding kernels' event pairs (the `kernels` extras) are taken over the same number of steps right AFTER it: four more
-    # event records per step between dependent kernels cost the step 0.02 ms (tools/exp_events.py: 1.85 against 1.83 ms).
-    vdb.index.profile(True)
+    # HIP events on the launch stream bracket the launches of the DOMINANT kernel (the scan) in every 4th step of the timed region:
+    # an event record between dependent kernels holds the next one back ~6 us (rocprofv3 trace, profiles/r4_*_step_trace.txt: 6.0-6.5 us
+    # before and after each of the step's two scan launches, 0.0 between the kernels without events), i.e. 0.024 ms per step when every
+    # step carries them.  The two embedding kernels' event pairs (the `kernels` extras) are taken right AFTER the timed region.
+    vdb.index.profile(True, every=4 if args.steps >= 8 else 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         emb, (D, I) = step()

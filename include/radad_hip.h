@@ -85,12 +85,15 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
  *                            mean before rounding the plane
  *   RADAD_KNN_OPT_SMALLQ_HI  1 (default) / 0: batches of <= 16 queries stream the f16 plane / the fp32 rows (twice the bytes)
  *   RADAD_KNN_OPT_WIDE_MIN_Q smallest batch that takes the 256-query tile scan instead of the streaming kernels (default 17)
+ *   RADAD_KNN_OPT_DENSE      1 (default) / 0: an fp32 store of <= 6144 rows (<= 16384 for <= 16 queries) is searched by writing out every
+ *                            score and selecting on them / by the register-list kernels
  * The environment variables RADAD_KNN_HI, RADAD_KNN_CENTRE, RADAD_KNN_SMALLQ_HI, RADAD_WIDE_MIN_Q override the DEFAULTS of handles
  * created while they are set (announced once per process on stderr); the product path never needs them. */
 #define RADAD_KNN_OPT_HI_PLANE 0
 #define RADAD_KNN_OPT_CENTRE 1
 #define RADAD_KNN_OPT_SMALLQ_HI 2
 #define RADAD_KNN_OPT_WIDE_MIN_Q 3
+#define RADAD_KNN_OPT_DENSE 4
 int radad_knn_set_option(radad_knn_t h, int option, int value);
 int radad_knn_destroy(radad_knn_t h);
 int radad_knn_dim(radad_knn_t h, int* dim);
@@ -175,6 +178,7 @@ int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, i
 #define RADAD_SCAN_F32_SMALLQ 2   /* <= 16 queries, fp32 rows streamed (4 bytes per element) */
 #define RADAD_SCAN_HI_SMALLQ 3    /* <= 16 queries, f16 plane / fp16 store streamed (2 bytes per element), certified */
 #define RADAD_SCAN_F16_TILE 4     /* fp16 store on the fp16-MFMA tile kernel without the certificate path */
+#define RADAD_SCAN_F32_DENSE 5    /* small fp32 store: every (row, query) score written out (fp32 MFMA), selection on the scores */
 int radad_knn_last_scan_kind(radad_knn_t h, int* kind);
 /* scan-kernel launches of the last search (the certified tile scan covers a large store in two: the first eighth with the
  * sample's admission floor, the rest with the floor the first eighth's candidates give); radad_knn_profile_read has one entry each */
@@ -199,9 +203,11 @@ int radad_knn_plane_rebuilds(radad_knn_t h, int* n_out);
 int radad_knn_last_recheck(radad_knn_t h, int* n_queries);
 int radad_knn_last_certificate(radad_knn_t h, int64_t* n_queries, int* stats6);
 
-/* HIP-event timing of the scan kernel (k_knn_f32) alone, on the stream each search is enqueued on:
- * enable -> every search records an event pair around the kernel launch (ring of 64); read synchronises on the
- * recorded events and returns the kernel durations in ms, oldest first.  For bench.py's roofline line. */
+/* HIP-event timing of the scan kernel alone, on the stream each search is enqueued on:
+ * enable = 1 -> every search records an event pair around each scan-kernel launch (ring of 64); enable = n > 1 -> every n-th search
+ * does (an event record between dependent kernels delays the next one by ~6 us: four per certified search of a large store);
+ * 0 -> off.  read synchronises on the recorded events and returns the kernel durations in ms, oldest first.  For bench.py's
+ * roofline line. */
 int radad_knn_profile(radad_knn_t h, int enable);
 int radad_knn_profile_read(radad_knn_t h, float* ms_out, int cap, int* n_out);
 
@@ -253,6 +259,21 @@ int radad_ivf_search(radad_ivf_t h, const float* q_dev, int64_t nq, int k, int n
  * search could return AND the ones its probing would have missed -- a superset of faiss.IndexIVFFlat's answer (which holds only rows
  * of the nprobe lists, vector_database.py:174-179), at the flat scan's cost, nprobe ignored.  0: the nprobe lists were scanned. */
 int radad_ivf_last_search_exact(radad_ivf_t h, int* exact_out);
+/* which list scan answered the most recent radad_ivf_search, and how many of its queries the f16 scan's certificate handed to the fp32
+ * pass (synchronises with that search):
+ *   RADAD_IVF_SCAN_F32         fp32 rows, v_mfma_f32_16x16x4_f32, k + 6 candidates per (query, list) re-ranked in float64 (dim % 64 != 0,
+ *                              no f16 plane, more probed lists than the re-rank stages, RADAD_IVF_OPT_HI_SCAN 0)
+ *   RADAD_IVF_SCAN_HI          the flat store's f16 plane gathered list-major, certified per query as the flat scan is; rejected queries
+ *                              are answered by the fp32 list scan in the same call
+ *   RADAD_IVF_SCAN_EXACT_FLAT  k > 26: the exact scan of the flat store (radad_ivf_last_search_exact) */
+#define RADAD_IVF_SCAN_F32 0
+#define RADAD_IVF_SCAN_HI 1
+#define RADAD_IVF_SCAN_EXACT_FLAT 2
+int radad_ivf_last_search_info(radad_ivf_t h, int* kind_out, int* rejected_out);
+/* RADAD_IVF_OPT_HI_SCAN 1 (default) / 0: list scans over the f16 plane / over the fp32 rows (A/B measurements; same results);
+ * 2 (tests): the f16 scan runs and every query is then treated as rejected by its certificate, i.e. answered by the fp32 pass */
+#define RADAD_IVF_OPT_HI_SCAN 0
+int radad_ivf_set_option(radad_ivf_t h, int option, int value);
 int radad_ivf_reconstruct(radad_ivf_t h, const int64_t* idx_dev, int64_t n, float* out_dev, void* stream);
 
 /* out[r] = the k-th largest of the groups x per_group values of row r, value (g, i) at in[(g n + r) per_group + i] -- the layout

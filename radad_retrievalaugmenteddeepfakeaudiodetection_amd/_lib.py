@@ -19,7 +19,9 @@ Q_F32, Q_BF16 = 0, 1
 OUT_F32, OUT_BF16 = 0, 1
 MAX_LEVELS = 8
 KNN_MAX_K = 1024
-KNN_OPT_HI_PLANE, KNN_OPT_CENTRE, KNN_OPT_SMALLQ_HI, KNN_OPT_WIDE_MIN_Q = 0, 1, 2, 3
+KNN_OPT_HI_PLANE, KNN_OPT_CENTRE, KNN_OPT_SMALLQ_HI, KNN_OPT_WIDE_MIN_Q, KNN_OPT_DENSE = 0, 1, 2, 3, 4
+IVF_OPT_HI_SCAN = 0
+IVF_SCAN_KINDS = ("f32_lists", "hi_lists", "exact_flat")
 EMBED_NO_SHARED_FRAMES, EMBED_LOGMEL_F32, EMBED_LOGMEL_DFT_GEMM = 1, 2, 4
 
 c_i64p = C.POINTER(C.c_int64)
@@ -110,6 +112,8 @@ SIGNATURES = {
     "radad_ivf_add": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "radad_ivf_search": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "radad_ivf_last_search_exact": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "radad_ivf_last_search_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "radad_ivf_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "radad_ivf_reconstruct": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "radad_rownorm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
     "radad_embed_create": (C.c_int, [C.POINTER(EmbedCfg), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

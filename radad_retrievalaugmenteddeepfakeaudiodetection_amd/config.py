@@ -59,6 +59,7 @@ class Config:
         self.knn_centre = None              # -1 / 0 / 1: decide per store / never / always centre the f16 plane
         self.knn_smallq_hi = None           # False: batches of <= 16 queries stream the fp32 rows
         self.knn_wide_min_q = None          # smallest batch on the 256-query tile scan (default 17)
+        self.knn_dense = None               # 0: fp32 stores of a few thousand rows stay on the register-list kernels
 
     def update(self, **kwargs):
         """config.py:109-115."""

@@ -82,8 +82,11 @@ struct EventRing {
     static constexpr int N = 64;
     hipEvent_t a[N], b[N];
     bool created = false, enabled = false;
+    bool active = true;          // this search is one of the sampled ones (next_search)
+    int every = 1, tick = 0;     // events around every `every`-th search only: an event record between dependent kernels costs ~6 us
     int count = 0;
-    int enable(bool on) {
+    void next_search() { active = (tick++ % every) == 0; }
+    int enable(bool on, int period = 1) {
         if (on && !created) {
             for (int i = 0; i < N; ++i) {
                 if (hipEventCreate(&a[i]) != hipSuccess || hipEventCreate(&b[i]) != hipSuccess) return RADAD_EHIP;
@@ -91,11 +94,12 @@ struct EventRing {
             created = true;
         }
         enabled = on;
+        every = period > 1 ? period : 1; tick = 0; active = true;
         count = 0;
         return RADAD_OK;
     }
-    void begin(hipStream_t st) { if (enabled) (void)hipEventRecord(a[count % N], st); }
-    void end(hipStream_t st) { if (enabled) { (void)hipEventRecord(b[count % N], st); ++count; } }
+    void begin(hipStream_t st) { if (enabled && active) (void)hipEventRecord(a[count % N], st); }
+    void end(hipStream_t st) { if (enabled && active) { (void)hipEventRecord(b[count % N], st); ++count; } }
     int read(float* out, int cap, int* n_out) {
         const int n = count < N ? count : N;
         int w = 0;

@@ -18,6 +18,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <atomic>
 #include <type_traits>
 #include <mutex>
 #include <new>
@@ -783,6 +784,107 @@ __global__ __launch_bounds__(SQ_THREADS, 2) void k_knn_f32_smallq(SmallQParams p
     }
 }
 
+// ---- a SMALL store (<= RF_STAGE_MAX rows: the IVF index's centroids, vector_database.py:65-70; a database of a few thousand files):
+// all scores, no lists.  The register-list kernels keep k + margin <= 32 candidates per (query, row slice) in sorted lists -- with
+// 4096 rows over 16 workgroups nearly every row is an insertion (k_knn_f32_smallq<32>: 0.14 ms for ONE query against 4096 x 512,
+// of which the 8 MB of rows are 1 us).  Here every (row, query) score is written out -- v_mfma_f32_16x16x4_f32 on the fp32
+// operands themselves, a wave per 16 rows x 16 queries -- as the query's candidate buffer in the emit-mode layout of the
+// certified tile scan (score [nq][plen], idx [nq][plen], cnt [nq] = n), and k_merge_refine<true> selects on its staged copy,
+// re-scores in float64 and certifies against eps(q) of the fp32 products (k_hi_rows, exact_ops).
+struct DenseParams {
+    const float* db; const float* ynorm; const float* q;      // fp32 store only
+    int64_t n;
+    int nq, dim, l2;
+    int plen;                   // row stride of score / idx: a multiple of 4, >= n
+    float* score; int* idx; int* cnt;
+};
+
+// <RT, QT>: 16-row x 16-query tiles per wave.  <1, 1> for the batches of <= 16 queries (one wave per 16 rows: parallel over the rows);
+// <2, 4> otherwise: 32 rows x 64 queries per wave -- every operand a wave loads feeds 4 resp. 2 MFMAs (<1, 1> on 1024 queries x 4096
+// centroids pulled 1 GB through the L2s for 4 GFLOP: 0.122 ms, the L2 bandwidth).
+template <int RT, int QT>
+__global__ __launch_bounds__(256) void k_knn_dense(DenseParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int64_t row0 = (int64_t)blockIdx.x * (64 * RT) + wave * (16 * RT);
+    const int q0 = blockIdx.y * (16 * QT);
+    if (row0 >= p.plen) return;
+    const float* pa[RT];
+    const float* pb[QT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) pa[r] = p.db + min(row0 + 16 * r + r16, p.n - 1) * p.dim + 4 * g;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) pb[t] = p.q + (int64_t)min(q0 + 16 * t + r16, p.nq - 1) * p.dim + 4 * g;
+    constexpr int NA = RT * QT == 1 ? 2 : 1;           // accumulators per tile (one tile alone: two chains hide the MFMA latency)
+    constexpr int KB = RT * QT == 1 ? 4 : 2;           // 16-element K blocks per panel; two panels in registers: the next one's loads
+                                                       // are in flight while the current one's MFMAs issue
+    f32x4 acc[RT][QT][NA];
+#pragma unroll
+    for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+#pragma unroll
+            for (int c = 0; c < NA; ++c) acc[r][t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkb = p.dim >> 4;
+    f32x4 a0[RT][KB], b0[QT][KB], a1[RT][KB], b1[QT][KB];
+    auto load = [&](f32x4 (&a)[RT][KB], f32x4 (&b)[QT][KB], int kp) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) {
+            const int kb = min(kp + u, nkb - 1);       // (a panel past the end re-reads the last block; its products are not used)
+#pragma unroll
+            for (int r = 0; r < RT; ++r) a[r][u] = *reinterpret_cast<const f32x4*>(pa[r] + kb * 16);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) b[t][u] = *reinterpret_cast<const f32x4*>(pb[t] + kb * 16);
+        }
+    };
+    auto mma = [&](const f32x4 (&a)[RT][KB], const f32x4 (&b)[QT][KB], int kp) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
+            if (kp + u < nkb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int t = 0; t < QT; ++t)
+                            acc[r][t][u % NA] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][u][j], b[t][u][j], acc[r][t][u % NA], 0, 0, 0);
+            }
+    };
+    load(a0, b0, 0);
+    for (int kp = 0; kp < nkb; kp += 2 * KB) {
+        load(a1, b1, kp + KB);
+        mma(a0, b0, kp);
+        load(a0, b0, kp + 2 * KB);
+        mma(a1, b1, kp + KB);
+    }
+    // acc[r][t][.][e]: row row0 + 16 r + 4 g + e, query q0 + 16 t + r16
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qq = q0 + 16 * t + r16;
+        if (qq >= p.nq) continue;
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int64_t rb = row0 + 16 * r + 4 * g;
+            f32x4 sc;
+            int id[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t row = rb + e;
+                float d = acc[r][t][0][e];
+                if (NA == 2) d += acc[r][t][NA - 1][e];
+                const bool on = row < p.n;
+                sc[e] = on ? (p.l2 ? 2.f * d - p.ynorm[row] : d) : -INFINITY;
+                id[e] = on ? (int)row : IDX_SENTINEL;
+            }
+            if (rb < p.plen) {
+                *reinterpret_cast<f32x4*>(p.score + (int64_t)qq * p.plen + rb) = sc;
+                *reinterpret_cast<int4*>(p.idx + (int64_t)qq * p.plen + rb) = make_int4(id[0], id[1], id[2], id[3]);
+            }
+        }
+        if (blockIdx.x == 0 && wave == 0 && g == 0) p.cnt[qq] = (int)p.n;
+    }
+}
+
 // ---- the same small-batch scan over the f16 plane (certified mode) -----------------------------------------------------
 // Half the bytes: the hi plane of an fp32 store (or an fp16 store itself) is streamed instead of the fp32 rows, one
 // v_mfma_f32_16x16x32_f16 per 32 elements of 16 rows against the f16-rounded queries in LDS.  The scores carry the error bound
@@ -1058,6 +1160,8 @@ struct RefineParams {
     int64_t* out_idx;         // [nq, k]
     double* out_key;          // optional [nq, k] float64 distances
     int debug;                // timing experiments only (-DRADAD_DEBUG_HOOKS, RADAD_DEBUG_KNN): 128 no statistics atomics, 256 no re-score, 512 no ranking, 1024 no fp32 funnel
+    int* qflag_out = nullptr;           // optional [nq] (certified mode): the certificate's verdict per query, 0 = certified (IVF: who takes the fp32 pass)
+    const int* only_flagged = nullptr;  // optional [nq]: workgroups of queries whose entry is 0 leave at once (IVF: the fp32 pass of the rejected)
 };
 
 // One workgroup (256 threads) per query: thread t looks after lists t, t + 256, ... (<= RF_MAXL of them); the k rounds
@@ -1077,19 +1181,21 @@ constexpr size_t refine_lds_bytes(int cap) { return (size_t)cap * 20 + 256; }   
 // walked entry by entry, i.e. 30-50 DEPENDENT trips to L2/HBM per query -- 0.17 ms for 1024 queries that re-score 150 rows
 // each, where the re-scoring itself needs a tenth of that.
 // The k-th largest of the NE scores staged in LDS (e_sc; -inf = "no entry", the smallest key), by a 4-pass radix select on the
-// order-preserving image of the float bits.  Only the VALUE is found.  Called by all RF_THREADS (= 256 = the bins) threads of the
+// order-preserving image of the float bits.  Only the VALUE is found.  Called by all NT (>= 256 = the bins) threads of the
 // block; hist [256] and xchg [2] are LDS scratch; e_sc needs no barrier of its own (the first pass's publishes it; so does the
 // early exit).  Returns -inf when NE < k.
+template <int NT = 256>
 __device__ __forceinline__ float radix_select_kth(const float* e_sc, int NE, int k, int* hist, int* xchg) {
+    static_assert(NT >= 256 && NT % 64 == 0, "one thread per bin at least");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     auto okey = [](float v) { const unsigned u = __float_as_uint(v); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
     unsigned prefix = 0, pmask = 0;
     int krem = k;
     const bool have_k = NE >= k;                                         // (block-uniform)
     for (int shift = 24; shift >= 0 && have_k; shift -= 8) {
-        hist[tid] = 0;                                                   // RF_THREADS == 256 bins
+        if (NT == 256 || tid < 256) hist[tid] = 0;                       // 256 bins
         __syncthreads();                                                 // (first pass: also publishes e_sc)
-        for (int i = tid; i < NE; i += RF_THREADS) {
+        for (int i = tid; i < NE; i += NT) {
             const unsigned key = okey(e_sc[i]);
             if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1);
         }
@@ -1199,6 +1305,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     int* e_id = reinterpret_cast<int*>(e_sc + (STAGED ? p.n_parts * p.part_len : 0));   // ... and rows; then the radix select's 256 bins
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t q = blockIdx.x;
+    if (p.only_flagged && !p.only_flagged[q]) return;                     // (workgroup-uniform)
     const bool cert = p.eps != nullptr;
     const float two_eps = cert ? 2.f * p.eps[q] : 0.f;
     const int64_t qbase = q * p.n_parts;
@@ -1372,6 +1479,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
         if (dropped_q) why |= 8;
         if (tid == 0) {
             if (why) p.flag_sel[atomicAdd(p.flag_count, 1)] = (int)q;
+            if (p.qflag_out) p.qflag_out[q] = why;
             if (p.stats && !RADAD_DBG(p.debug, 128)) {
                 atomicAdd(&p.stats[0], nsel);
                 for (int b2 = 0; b2 < 4; ++b2) if (why & (1 << b2)) atomicAdd(&p.stats[1 + b2], 1);
@@ -1386,7 +1494,9 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     //     (s_j - e_j > s_c + e_c) cannot be among the exact k best and is dropped; only the survivors -- k plus the few within
     //     ~1e-6 of the k-th -- go through the float64 re-score and the ranking, whose cost is linear resp. quadratic in the
     //     count (with 150 candidates per query they were two thirds of this kernel).
-    if (cert && nsel > p.k && !RADAD_DBG(p.debug, 1024)) {
+    //     (a handful beyond k -- the fp32 scans' candidates, the IVF index's coarse step -- go straight to float64: the funnel's pass over
+    //     their rows costs what it saves)
+    if (cert && nsel > p.k + 16 && !RADAD_DBG(p.debug, 1024)) {
         float2* f_lh = reinterpret_cast<float2*>(c_key);                 // (s - e, s + e) per candidate; c_key is free until 2)
         int* tmp_id = reinterpret_cast<int*>(c_gid);                     // survivors' rows; c_gid is free until 3)
         const float gamma = (float)(p.dim / 16 + 8) * 5.9604645e-08f * 1.01f;
@@ -1580,6 +1690,178 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     }
 }
 
+// ---- the re-rank of a SMALL batch (<= 16 queries: the online predict() search, pipeline.py:1038-1054) -------------------------
+// k_merge_refine is one 256-thread workgroup per query: with one query that is ONE workgroup walking 500-800 partial lists (the
+// streaming kernels write one per workgroup) and re-scoring its candidates 16 lanes at a time -- 0.123 ms of the reference's own
+// search (25 423 x 5376, k 15), twice its scan; 45 us on the 1 M x 512 store.  Where the time went: the radix select's LDS-atomic
+// histogram over all 16 K staged entries (~30 us), then 11 dependent sweeps of row loads per re-score pass, twice (fp32 funnel,
+// float64).  This form:
+//   * RS_SPLIT workgroups of 1024 threads per query, thread t <-> partial list t (<= RS_MAX_PARTS lists, sorted best-first);
+//   * tau from the list HEADS only: h_k = the k-th largest head is a lower bound of a_k (k different lists reach it), so
+//     tau = h_k - 2 eps admits every row the certificate needs (knn.hip: k_merge_refine's header) -- and, the store being split
+//     over hundreds of lists, hardly any more (h_k = a_k unless two of the k best rows share a list);
+//   * the lists are walked while their entries are >= tau (sorted: usually 0 or 1 step), slots by a block prefix sum -- every
+//     workgroup of the query computes the same candidate list;
+//   * float64 re-score of ALL candidates (no fp32 funnel: there are few), one WAVE per candidate with the row's loads of a sweep
+//     (4096 elements) in flight together, the candidates dealt round-robin to the RS_SPLIT x 16 waves of the query;
+//   * the keys meet in global memory; the workgroup that arrives last (device-scope counter, as k_exact_scan's slices) ranks
+//     them, writes the result and the certificate's verdict.
+constexpr int RS_THREADS = 1024;
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_SPLIT = 8;
+constexpr int RS_MAX_PARTS = RS_THREADS;
+constexpr size_t refine_small_lds_bytes(int cap) { return (size_t)cap * 20 + (size_t)RS_MAX_PARTS * 4 + 256 * 4 + 256; }
+
+__global__ __launch_bounds__(RS_THREADS) void k_refine_small(RefineParams p, double* __restrict__ wkey, int* __restrict__ wcount) {
+    extern __shared__ __attribute__((aligned(16))) char smem_s[];
+    double* c_key = reinterpret_cast<double*>(smem_s);                   // [cap]
+    int64_t* c_gid = reinterpret_cast<int64_t*>(c_key + p.cap);          // [cap]
+    int* c_id = reinterpret_cast<int*>(c_gid + p.cap);                   // [cap]
+    float* heads = reinterpret_cast<float*>(c_id + p.cap);               // [RS_MAX_PARTS]
+    int* hist = reinterpret_cast<int*>(heads + RS_MAX_PARTS);            // [256]
+    int* xch = hist + 256;                                               // [2] select, [16] wave counts, [1] arrival
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.x;
+    const int64_t q = blockIdx.y;
+    const float two_eps = 2.f * p.eps[q];
+    const float floor_q = p.thr_init ? p.thr_init[q] : -INFINITY;
+    const int dropped_q = p.qflag ? p.qflag[q] : 0;
+    const int64_t lb = (q * p.n_parts + tid) * p.part_len;               // this thread's list
+    const bool have = tid < p.n_parts;
+
+    int hid = IDX_SENTINEL;
+    float hs = -INFINITY;
+    if (have) { hid = p.idx[lb]; const float s0 = p.score[lb]; if (hid != IDX_SENTINEL) hs = s0; }
+    heads[tid] = hs;
+    const float h_k = radix_select_kth<RS_THREADS>(heads, p.n_parts, p.k, hist, xch);
+    float tau = h_k > -INFINITY ? h_k - two_eps : -INFINITY;             // (fewer than k lists: everything listed goes on)
+    if (p.global_lb) tau = fmaxf(tau, p.global_lb[q] - 0.5f * two_eps);  // (sharded search: see k_merge_refine)
+    int cnt = 0, used_up = 0;
+    if (have && hid != IDX_SENTINEL && hs >= tau) {
+        cnt = 1;
+        while (cnt < p.part_len) {
+            const int id = p.idx[lb + cnt];
+            if (id == IDX_SENTINEL || !(p.score[lb + cnt] >= tau)) break;
+            ++cnt;
+        }
+        if (cnt == p.part_len) used_up = 1;                              // a FULL list of entries >= tau may hide more such rows
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) xch[2 + wave] = incl;
+    used_up = __syncthreads_or(used_up);
+    int base_slot = incl - cnt, total = 0;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) { const int c = xch[2 + w]; if (w < wave) base_slot += c; total += c; }
+    for (int j = 0; j < cnt; ++j)
+        if (base_slot + j < p.cap) c_id[base_slot + j] = j == 0 ? hid : p.idx[lb + j];
+    int nsel = total, why = 0;
+    if (nsel > p.cap) { nsel = p.cap; why |= 1; }
+    if (used_up) why |= 2;
+    if (floor_q > -INFINITY && !(floor_q <= tau)) why |= 4;
+    if (dropped_q) why |= 8;
+    __syncthreads();                                                     // c_id complete
+
+    // float64 re-score: wave (r, wave) takes candidates r * 16 + wave, + RS_SPLIT * 16, ...
+    {
+        const float* qrow = p.q + q * p.dim;
+        for (int c = r * RS_WAVES + wave; c < nsel; c += RS_SPLIT * RS_WAVES) {
+            const int64_t rid = (int64_t)c_id[c];
+            double acc = 0.0;
+            for (int i0 = 0; i0 < p.dim; i0 += 4096) {                   // 64 lanes x 16 x 4 elements per sweep
+                f32x4 b[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = i0 + (u * 64 + lane) * 4;
+                    b[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (i < p.dim) {
+                        if (p.db_f16) {
+                            const f16x4 h4 = *reinterpret_cast<const f16x4*>(reinterpret_cast<const _Float16*>(p.db) + rid * p.dim + i);
+                            b[u] = f32x4{(float)h4[0], (float)h4[1], (float)h4[2], (float)h4[3]};
+                        } else {
+                            b[u] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.db) + rid * p.dim + i);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int i = i0 + (u * 64 + lane) * 4;
+                    if (i < p.dim) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + i);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (p.l2) { const double d = (double)a[e] - (double)b[u][e]; acc += d * d; }
+                            else acc += (double)a[e] * (double)b[u][e];
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int ofs = 32; ofs > 0; ofs >>= 1) acc += __shfl_xor(acc, ofs, 64);
+            if (lane == 0) wkey[q * p.cap + c] = acc;
+        }
+    }
+    __threadfence();                                     // release: this workgroup's keys are visible device-wide before the counter moves
+    __syncthreads();
+    if (tid == 0) {
+        const int old = atomicAdd(&wcount[q], 1);
+        xch[18] = old == RS_SPLIT - 1;
+        if (old == RS_SPLIT - 1) wcount[q] = 0;          // ready for the next search
+    }
+    __syncthreads();
+    if (!xch[18]) return;                                // (workgroup-uniform)
+    __threadfence();                                     // acquire
+    if (tid == 0) {
+        if (why) p.flag_sel[atomicAdd(p.flag_count, 1)] = (int)q;
+        if (p.stats) {
+            atomicAdd(&p.stats[0], nsel);
+            for (int b2 = 0; b2 < 4; ++b2) if (why & (1 << b2)) atomicAdd(&p.stats[1 + b2], 1);
+        }
+    }
+    // rank by (distance, id), as k_merge_refine's step 3
+    for (int c = tid; c < nsel; c += RS_THREADS) {
+        c_gid[c] = p.id_map ? p.id_map[c_id[c]] : (int64_t)c_id[c];
+        double kc = __builtin_nontemporal_load(&wkey[q * p.cap + c]);
+        if (p.l2) kc = -kc;
+        if (kc != kc) kc = -(double)INFINITY;            // a NaN key ranks last, among its kind by id
+        c_key[c] = kc;
+    }
+    __syncthreads();
+    {
+        const int T = nsel <= 256 ? 4 : 2;               // (nsel <= cap <= 512)
+        const int part = tid & (T - 1);
+        for (int c0 = 0; c0 < nsel; c0 += RS_THREADS / T) {
+            const int c = c0 + tid / T;
+            const bool onc = c < nsel;
+            const double kc = onc ? c_key[c] : 0.0;
+            const int64_t ic = onc ? c_gid[c] : 0;
+            int rank = 0;
+            for (int j = part; j < nsel; j += T) {
+                const double kj = c_key[j];
+                const int64_t ij = c_gid[j];
+                rank += (int)((kj > kc) | ((kj == kc) & (ij < ic)));
+            }
+            rank += __shfl_xor(rank, 1, 64);
+            if (T == 4) rank += __shfl_xor(rank, 2, 64);
+            if (onc && part == 0 && rank < p.k) {
+                const double kd = p.l2 ? -kc : kc;
+                p.out_dist[q * p.k + rank] = (float)kd;
+                p.out_idx[q * p.k + rank] = ic + p.id_base;
+                if (p.out_key) p.out_key[q * p.k + rank] = kd;
+            }
+        }
+    }
+    for (int o = nsel + tid; o < p.k; o += RS_THREADS) {   // faiss fills what it cannot find with -1 / +-inf
+        p.out_dist[q * p.k + o] = p.l2 ? INFINITY : -INFINITY;
+        p.out_idx[q * p.k + o] = -1;
+        if (p.out_key) p.out_key[q * p.k + o] = p.l2 ? (double)INFINITY : -(double)INFINITY;
+    }
+}
+
 // ---- exact float64 search of the queries the certificate rejected --------------------------------------------------
 // Driven entirely from the device: the number of queries (*count) and their indices (sel) were written by
 // k_merge_refine; the launch geometry is fixed, workgroups with nothing to do leave at once.  Slice s of the store
@@ -1606,7 +1888,8 @@ struct ExactParams {
     int* pidx;
     int64_t id_base;
     float* out_dist; int64_t* out_idx; double* out_key;
-    int* host_stats;           // pinned host memory (device-visible): the kernel leaves the search's 6 counters there
+    int* host_stats;           // pinned host memory (device-visible): the kernel leaves the search's 6 counters there, then ...
+    int stamp;                 // ... this value in host_stats[6] (the search's sequence number + 1): the host reads a report only when its stamp is there
     int* arrive;               // [query groups] arrival counters of the slices (zero between launches: the last arrival resets its own)
 };
 
@@ -1615,7 +1898,11 @@ __device__ __forceinline__ void exact_merge_slot(const ExactParams& p, int slot,
 
 __global__ __launch_bounds__(KX_THREADS) void k_exact_scan(ExactParams p) {
     const int count = *p.count;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 6 && p.host_stats) p.host_stats[threadIdx.x] = p.count[threadIdx.x];   // count + 5 statistics
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && p.host_stats) {
+        for (int i = 0; i < 6; ++i) p.host_stats[i] = p.count[i];       // count + 5 statistics
+        __threadfence_system();
+        *reinterpret_cast<volatile int*>(&p.host_stats[6]) = p.stamp;
+    }
     if (count <= 0) return;
     __shared__ int s_last;
     extern __shared__ __attribute__((aligned(16))) char smem_x[];
@@ -1991,6 +2278,7 @@ struct SearchCtx {
     int64_t nq = 0;
     int k = 0, l2 = 0, cslot = 0, n_parts = 0, plen = 0, cap = 0, xgroup = 1;
     bool cert = false, emit = false, use_floor = false;
+    bool small_lists = false;          // the streaming kernels' output: one SORTED list per workgroup and query (k_refine_small)
     bool canonical = false;            // the scan's scores estimate q.y / -|q - y|^2 themselves (comparable across shards); the fp32
                                        // kernels' L2 score 2 q.y - |y|^2 lacks the -|q|^2: a cross-shard bound does not apply to it
     const float* q_use = nullptr;       // fp32 queries as the re-rank reads them (caller's buffer, or the workspace's normalised copy)
@@ -2016,6 +2304,7 @@ struct radad_knn_s {
     int opt_centre = -1;         // -1: decided per store from |mean|^2 / mean |y|^2; 0 never, 1 always
     int opt_smallq_hi = 1;       // small batches stream the f16 plane (0: the fp32 rows)
     int opt_wide_min_q = 17;     // smallest batch that takes the 256-query tile scan
+    int opt_dense = 1;           // stores of <= RF_STAGE_MAX rows: all scores + select (k_knn_dense) instead of the register-list kernels
     unsigned* stat = nullptr;    // device [3] float bits: max |y'|, max |y' - yh| (y' = y - mu when the plane is centred, else y) and
                                  // max |y| over rows [0, stat_rows)
     int64_t stat_rows = 0;
@@ -2028,6 +2317,8 @@ struct radad_knn_s {
     int64_t kacc_tiles = 0;
     int* xarrive = nullptr;      // exact pass: arrival counters of the query groups (zero between launches)
     int64_t xarrive_cap = 0;
+    double* rs_key = nullptr;    // k_refine_small: [SQ_NQ][KNN_CERT_CAP] float64 keys of the candidates, where the query's workgroups meet
+    int* rs_count = nullptr;     // ... and [SQ_NQ] arrival counters (zero between launches)
     int uniform_e = HI_E_PER_ROW; // one power-of-two scale 2^e for every row of the plane (rows of one magnitude), or HI_E_PER_ROW
     // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
     // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
@@ -2035,11 +2326,13 @@ struct radad_knn_s {
     // then: the host is never more than two searches ahead of the device), so which kernels a search sequence runs does not depend
     // on host / device timing -- the first version polled the previous search's event with hipEventQuery and could take the f16
     // scan in one run and the fp32 scan in another.
-    int* host_count = nullptr;   // pinned [2][8]: rejected queries, sum of candidates, rejections by reason x 4
+    int* host_count = nullptr;   // pinned [2][8]: rejected queries, sum of candidates, rejections by reason x 4, [6] the report's stamp
+    bool owned_serial = false;   // the handle is private to another object that orders its calls itself (the IVF index's centroid store): no ev_done
     int* host_count_dev = nullptr;   // the same memory as the device sees it
-    hipEvent_t ev_count[2] = {nullptr, nullptr}, ev_done = nullptr;
+    hipEvent_t ev_done = nullptr;
     hipEvent_t ev_begun = nullptr;      // end of radad_knn_search_begin's device work: _finish waits for it (it may run on another stream)
-    bool count_pending[2] = {false, false}, done_recorded = false;
+    bool done_recorded = false;
+    hipStream_t last_stream = nullptr;   // where the last search was enqueued (owned_serial handles synchronise on it for the statistics)
     int64_t count_nq[2] = {0, 0};    // batch size of the search a slot belongs to
     uint64_t search_seq = 0;     // certified searches so far
     int hi_skip = 0;             // searches left on the fp32 kernels after the certified scan rejected too many queries
@@ -2358,8 +2651,6 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
     {
         DeviceGuard g(device);
         if (hipHostMalloc(reinterpret_cast<void**>(&h->host_count), 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_count[0], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&h->ev_count[1], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_begun, hipEventDisableTiming) != hipSuccess) {
             radad_set_error("radad_knn_create: pinned counter / events could not be created");
@@ -2392,8 +2683,9 @@ int radad_knn_destroy(radad_knn_t h) {
         if (h->kacc) (void)hipFree(h->kacc);
         if (h->kflag) (void)hipFree(h->kflag);
         if (h->xarrive) (void)hipFree(h->xarrive);
+        if (h->rs_key) (void)hipFree(h->rs_key);
+        if (h->rs_count) (void)hipFree(h->rs_count);
         if (h->host_count) (void)hipHostFree(h->host_count);
-        for (int i = 0; i < 2; ++i) if (h->ev_count[i]) (void)hipEventDestroy(h->ev_count[i]);
         if (h->ev_done) (void)hipEventDestroy(h->ev_done);
         if (h->ev_begun) (void)hipEventDestroy(h->ev_begun);
         h->prof.destroy();
@@ -2427,6 +2719,10 @@ int radad_knn_set_option(radad_knn_t h, int option, int value) {
         case RADAD_KNN_OPT_WIDE_MIN_Q:
             RADAD_REQUIRE(value >= 1, "radad_knn_set_option: WIDE_MIN_Q must be >= 1");
             h->opt_wide_min_q = value;
+            return RADAD_OK;
+        case RADAD_KNN_OPT_DENSE:
+            RADAD_REQUIRE(value == 0 || value == 1, "radad_knn_set_option: DENSE takes 0 or 1");
+            h->opt_dense = value;
             return RADAD_OK;
         default:
             radad_set_error("radad_knn_set_option: unknown option %d", option);
@@ -2587,18 +2883,27 @@ static int knn_tile_ksplit(radad_knn_t h, int qtiles_grid, int n_splits, int64_t
 // and scans, and can report per query a lower bound of the exact k-th best score of THIS store; phase 2 re-ranks -- with the
 // maximum of the shards' bounds, only what can still be among the global k best -- and runs the exact kernel.
 
+// the most recent search's device work is complete (its statistics are in the pinned host copy)
+static hipError_t knn_wait_last_search(radad_knn_t h) {
+    if (h->done_recorded) return hipEventSynchronize(h->ev_done);
+    if (h->owned_serial) return hipStreamSynchronize(h->last_stream);
+    return hipSuccess;
+}
+
 static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64_t nq, int k, int margin, float* lb_out, hipStream_t st,
                              SearchCtx* ctx) {
     // one workspace per handle: a search on another stream waits for the previous one (threads are serialised by h->mu,
     // the device work by this event)
     if (h->done_recorded) RADAD_HIP_CHECK(hipStreamWaitEvent(st, h->ev_done, 0));
 
+    h->prof.next_search();
     const bool cert = k <= KNN_CERT_MAX_K;      // beyond: legacy k + margin candidates, no certificate
     // how the certificate of the search TWO back fared (fixed lag: see the handle); this search takes over its slot
     const int cslot = (int)(h->search_seq & 1);
-    if (cert && h->count_pending[cslot]) {
-        RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count[cslot]));
-        h->count_pending[cslot] = false;
+    // (until round 4 an event behind every search was waited for here: an event record between dependent kernels costs the stream ~6 us,
+    // a tenth of an online search.  The exact kernel now stamps its report; one that has not arrived yet is simply not looked at.)
+    if (cert && h->search_seq >= 2 && *reinterpret_cast<volatile int*>(&h->host_count[8 * cslot + 6]) == (int)((h->search_seq - 2) & 0x3fffffff) + 1) {
+        std::atomic_thread_fence(std::memory_order_acquire);
         // (the report is that of search search_seq - 2: if the plane or the buffers were changed since, it says nothing about them)
         if (h->hi_skip == 0 && h->count_nq[cslot] >= 64 && (int64_t)h->host_count[8 * cslot] * 4 > h->count_nq[cslot] &&
             h->search_seq >= h->tuned_at + 2) {
@@ -2662,7 +2967,11 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         if (h->hi_skip > 0) --h->hi_skip;
         else smallq_hi = knn_ensure_hi(h, st, true);
     }
-    const bool smallq = smallq_geom && !smallq_hi && !h->f16 && h->dim % 32 == 0 && sq_lds_f32 <= SQ_LDS_BUDGET;
+    // a small fp32 store (the IVF index's centroids; a database of a few thousand files): every score + select on the staged copy
+    const int dense_plen = (int)((std::max<int64_t>(h->ntotal, 1) + 3) / 4 * 4);
+    const bool dense = cert && !use_hi && !smallq_hi && !h->f16 && h->opt_dense && h->ntotal >= 1 &&
+                       h->ntotal <= (nq <= SQ_NQ ? RF_STAGE_MAX_SMALLQ : RF_STAGE_MAX) && h->dim % 16 == 0 && nq * (int64_t)dense_plen <= ((int64_t)1 << 24);
+    const bool smallq = smallq_geom && !dense && !smallq_hi && !h->f16 && h->dim % 32 == 0 && sq_lds_f32 <= SQ_LDS_BUDGET;
     int sq_rows_per_wave = 0;
     // a small store of wide rows (the reference's own: 25 423 x 5376) has too few 16-row steps to occupy the chip with one wave per
     // row slice: the K-split form puts four waves on every step
@@ -2670,7 +2979,9 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     // (its lists are 16 entries for k <= 16 -- the reference's k = 15 included -- instead of k + 6 <= 32: half the list registers,
     // twice the waves per SIMD to hide the HBM latency behind.  A workgroup whose 16-entry list is used up by rows within the
     // threshold rejects the query; the exact kernel over so small a store costs ~0.3 ms)
-    const int ksel_sq = (sq_ksplit && k <= 16) ? 16 : ksel;
+    // (the same 16-entry lists on every f16 small-batch scan since round 4: k_knn_hi_smallq<32> streams the 1 M x 512 store in 0.40 ms,
+    // <16> in 0.20 -- 155 VGPRs against the 32-entry lists' panel of half the loads in flight)
+    const int ksel_sq = (smallq_hi && k <= 16) ? 16 : ksel;
     if (sq_ksplit) {
         int64_t rpg = 16;
         while (ceil_div64(h->ntotal, rpg) * ksel_sq > RF_STAGE_MAX_SMALLQ) rpg += 16;
@@ -2683,11 +2994,11 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         // one full round of resident waves: 1024 SIMDs x the waves per SIMD the kernel's registers allow (k_knn_hi_smallq<16>: 155
         // VGPRs = 3; the 32-entry and fp32 variants: 2).  (Measured: no difference against 2048 waves on the 1 M x 512 store -- 0.2075
         // vs 0.208 ms, 4.93 TB/s either way: the stream is not limited by the number of waves in flight.)
-        const int64_t waves_wanted = 1024 * ((smallq_hi && ksel <= 16) ? 3 : 2);
+        const int64_t waves_wanted = 1024 * ((smallq_hi && ksel_sq <= 16) ? 3 : 2);
         const size_t rb = smallq_hi ? (size_t)h->dim * 2 : (size_t)h->dim * 4;
         const int64_t rows_min = std::max<int64_t>(16, std::min<int64_t>(128, ceil_div64(ceil_div64(128 * 1024, (int64_t)rb), 16) * 16));
         int64_t rpw = std::max<int64_t>(ceil_div64(ceil_div64(h->ntotal, waves_wanted), 16) * 16, rows_min);
-        while (rpw < 128 && ceil_div64(ceil_div64(h->ntotal, rpw), 4) * ksel > RF_STAGE_MAX_SMALLQ) rpw += 16;
+        while (rpw < 128 && ceil_div64(ceil_div64(h->ntotal, rpw), 4) * ksel_sq > RF_STAGE_MAX_SMALLQ) rpw += 16;
         sq_rows_per_wave = (int)rpw;
         n_splits = (int)ceil_div64(ceil_div64(h->ntotal, rpw), 4);                // workgroups of 4 waves = lists per query
         n_qtiles = 1;
@@ -2700,11 +3011,12 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     const int64_t hi_phase0 = (int64_t)8 * s_splits * KW_M;
     const int emit_cap = use_hi ? std::min(RF_STAGE_MAX, std::max(1024 * h->cap_boost, 32 * ksel)) : 0;
     h->last_qtiles = n_qtiles;
-    h->last_threads = use_hi ? KW_THREADS : ((smallq || smallq_hi) ? SQ_THREADS : KNN_THREADS);
-    h->last_kind = use_hi ? RADAD_SCAN_HI_TILE : smallq_hi ? RADAD_SCAN_HI_SMALLQ : smallq ? RADAD_SCAN_F32_SMALLQ
+    if (dense) { n_qtiles = (int)ceil_div64(nq, 16); n_splits = 1; }
+    h->last_threads = use_hi ? KW_THREADS : ((smallq || smallq_hi || dense) ? SQ_THREADS : KNN_THREADS);
+    h->last_kind = use_hi ? RADAD_SCAN_HI_TILE : dense ? RADAD_SCAN_F32_DENSE : smallq_hi ? RADAD_SCAN_HI_SMALLQ : smallq ? RADAD_SCAN_F32_SMALLQ
                           : f16_tile ? RADAD_SCAN_F16_TILE : RADAD_SCAN_F32_TILE;
-    const int plen = use_hi ? emit_cap : ksel_sq;   // entries of a partial list / of the candidate buffer
-    const int n_parts = use_hi ? 1 : n_splits;
+    const int plen = use_hi ? emit_cap : dense ? dense_plen : ksel_sq;   // entries of a partial list / of the candidate buffer
+    const int n_parts = (use_hi || dense) ? 1 : n_splits;
     const int cap = cert ? std::max(k + KNN_CERT_EXTRA, KNN_CERT_CAP) : ksel;
     const int xgroup = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(64 * 1024) / ((size_t)h->dim * 4)));
 
@@ -2903,6 +3215,14 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             if (FILE* f = fopen(getenv("RADAD_KNN_STAMPS"), "wb")) { fwrite(hs.data(), 8, hs.size(), f); fclose(f); }
         }
 #endif
+    } else if (dense) {
+        DenseParams dp;
+        dp.db = (const float*)h->rows; dp.ynorm = h->ynorm; dp.q = q_use; dp.n = h->ntotal; dp.nq = (int)nq; dp.dim = h->dim; dp.l2 = l2;
+        dp.plen = dense_plen; dp.score = ps; dp.idx = pi; dp.cnt = cand_cnt;
+        h->prof.begin(st);
+        if (nq <= SQ_NQ) hipLaunchKernelGGL((k_knn_dense<1, 1>), dim3((unsigned)ceil_div64(dense_plen, 64), (unsigned)ceil_div64(nq, 16)), dim3(256), 0, st, dp);
+        else hipLaunchKernelGGL((k_knn_dense<2, 4>), dim3((unsigned)ceil_div64(dense_plen, 128), (unsigned)ceil_div64(nq, 64)), dim3(256), 0, st, dp);
+        h->prof.end(st);
     } else if (smallq_hi) {
         SmallQHiParams sp;
         sp.db = h->f16 ? (const _Float16*)h->rows : h->hi;
@@ -2921,7 +3241,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             if (ksel_sq <= 16) hipLaunchKernelGGL(k_knn_hi_smallq_ksplit<16>, sgrid, dim3(SQ_THREADS), lds, st, sp);
             else hipLaunchKernelGGL(k_knn_hi_smallq_ksplit<32>, sgrid, dim3(SQ_THREADS), lds, st, sp);
             h->prof.end(st);
-        } else if (ksel <= 16) {
+        } else if (ksel_sq <= 16) {
             RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_knn_hi_smallq<16>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             h->prof.begin(st);
@@ -2997,7 +3317,8 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
 
     ctx->valid = true;
     ctx->nq = nq; ctx->k = k; ctx->l2 = l2; ctx->cslot = cslot; ctx->n_parts = n_parts; ctx->plen = plen; ctx->cap = cap; ctx->xgroup = xgroup;
-    ctx->cert = cert; ctx->emit = use_hi; ctx->use_floor = use_hi; ctx->q_use = q_use;
+    ctx->cert = cert; ctx->emit = use_hi || dense; ctx->use_floor = use_hi; ctx->q_use = q_use;
+    ctx->small_lists = !use_hi && !dense && (smallq || smallq_hi);
     ctx->canonical = use_hi || smallq_hi || !l2;
     ctx->have_ak = lb_out != nullptr && use_hi && cert; ctx->o_ak = o_ak;
     ctx->o_eps = o_eps; ctx->o_thr = o_thr; ctx->o_cnt = o_cnt; ctx->o_fcount = o_fcount; ctx->o_fsel = o_fsel; ctx->o_ps = o_ps; ctx->o_pi = o_pi;
@@ -3029,9 +3350,26 @@ static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* glo
     m.stats = c.cert ? flag_count + 1 : nullptr;
     RADAD_REQUIRE(c.n_parts <= RF_THREADS * RF_MAXL, "radad_knn_search: %d partial lists per query exceed the re-rank kernel's %d", c.n_parts,
                   RF_THREADS * RF_MAXL);
-    {   // certified mode with lists that fit the LDS: selection on a staged copy (one round of loads instead of a pointer chase)
+    if (c.cert && c.small_lists && nq <= SQ_NQ && m.n_parts <= RS_MAX_PARTS && m.cap <= KNN_CERT_CAP + KNN_CERT_MAX_K) {
+        // a small batch: RS_SPLIT workgroups per query (k_refine_small)
+        if (!h->rs_key) {                                // (once per handle: allocation and clearing synchronise)
+            const size_t kb = (size_t)SQ_NQ * (KNN_CERT_CAP + KNN_CERT_MAX_K) * sizeof(double);
+            if (hipMalloc((void**)&h->rs_key, kb) != hipSuccess || hipMalloc((void**)&h->rs_count, SQ_NQ * sizeof(int)) != hipSuccess ||
+                hipMemset(h->rs_count, 0, SQ_NQ * sizeof(int)) != hipSuccess) {
+                (void)hipGetLastError();
+                if (h->rs_key) (void)hipFree(h->rs_key);
+                if (h->rs_count) (void)hipFree(h->rs_count);
+                h->rs_key = nullptr; h->rs_count = nullptr;
+                radad_set_error("hipMalloc of the small-batch re-rank's buffers failed");
+                return RADAD_ENOMEM;
+            }
+        }
+        const size_t rlds = refine_small_lds_bytes(c.cap);
+        hipLaunchKernelGGL(k_refine_small, dim3(RS_SPLIT, (unsigned)nq), dim3(RS_THREADS), rlds, st, m, h->rs_key, h->rs_count);
+    } else {   // certified mode with lists that fit the LDS: selection on a staged copy (one round of loads instead of a pointer chase)
         const size_t entries = (size_t)m.n_parts * m.part_len;
-        RADAD_REQUIRE(!c.emit || (m.eps && entries <= (size_t)RF_STAGE_MAX), "radad_knn_search: candidate buffer larger than the re-rank stages");
+        RADAD_REQUIRE(!c.emit || (m.eps && entries <= (size_t)(nq <= SQ_NQ ? RF_STAGE_MAX_SMALLQ : RF_STAGE_MAX)),
+                      "radad_knn_search: candidate buffer larger than the re-rank stages");
         if (m.eps && entries <= (size_t)(nq <= SQ_NQ ? RF_STAGE_MAX_SMALLQ : RF_STAGE_MAX)) {
             const size_t rlds = refine_lds_bytes(c.cap) + entries * 8 + 1024;
             if (rlds > 48 * 1024)
@@ -3051,7 +3389,7 @@ static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* glo
         x.slice_rows = ceil_div64(std::max<int64_t>(h->ntotal, 1), KX_SLICES);
         x.pkey = (double*)(ws + c.o_xk); x.pidx = (int*)(ws + c.o_xi); x.id_base = h->id_base;
         x.out_dist = out_dist_dev; x.out_idx = out_idx_dev; x.out_key = out_key_dev;
-        x.host_stats = h->host_count_dev + 8 * c.cslot;
+        x.host_stats = h->host_count_dev + 8 * c.cslot; x.stamp = (int)(h->search_seq & 0x3fffffff) + 1;
         const size_t xlds = (size_t)c.xgroup * h->dim * 4 + (size_t)KX_WAVES * c.xgroup * k * 12 + 16;
         RADAD_REQUIRE(xlds <= 160 * 1024, "radad_knn_search: dim %d x k %d too large for the exact kernel", h->dim, k);
         RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_exact_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
@@ -3072,13 +3410,14 @@ static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* glo
         x.arrive = h->xarrive;
         hipLaunchKernelGGL(k_exact_scan, dim3(KX_SLICES, KX_GROUPS_Y), dim3(KX_THREADS), xlds, st, x);
         RADAD_HIP_CHECK(hipGetLastError());
-        RADAD_HIP_CHECK(hipEventRecord(h->ev_count[c.cslot], st));      // (k_exact_scan has written the counters to the pinned host copy)
-        h->count_pending[c.cslot] = true;
-        h->count_nq[c.cslot] = nq;
+        h->count_nq[c.cslot] = nq;                                     // (k_exact_scan writes the counters and its stamp to the pinned host copy)
         ++h->search_seq;
     }
-    RADAD_HIP_CHECK(hipEventRecord(h->ev_done, st));
-    h->done_recorded = true;
+    if (!h->owned_serial) {
+        RADAD_HIP_CHECK(hipEventRecord(h->ev_done, st));
+        h->done_recorded = true;
+    }
+    h->last_stream = st;
     return RADAD_OK;
 }
 
@@ -3211,7 +3550,7 @@ int radad_knn_profile(radad_knn_t h, int enable) {
     RADAD_REQUIRE(h, "NULL handle");
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
-    int rc = h->prof.enable(enable != 0);
+    int rc = h->prof.enable(enable != 0, enable);
     if (rc) radad_set_error("hipEventCreate failed");
     return rc;
 }
@@ -3230,7 +3569,7 @@ int radad_knn_last_recheck(radad_knn_t h, int* n_queries) {
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
     const int ls = (int)((h->search_seq + 1) & 1);       // slot of the most recent certified search
-    if (h->count_pending[ls]) RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count[ls]));
+    RADAD_HIP_CHECK(knn_wait_last_search(h));
     *n_queries = (h->host_count && h->search_seq) ? h->host_count[8 * ls] : 0;
     return RADAD_OK;
 }
@@ -3240,7 +3579,7 @@ int radad_knn_last_certificate(radad_knn_t h, int64_t* n_queries, int* stats6) {
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
     const int ls = (int)((h->search_seq + 1) & 1);       // slot of the most recent certified search
-    if (h->count_pending[ls]) RADAD_HIP_CHECK(hipEventSynchronize(h->ev_count[ls]));
+    RADAD_HIP_CHECK(knn_wait_last_search(h));
     for (int i = 0; i < 6; ++i) stats6[i] = (h->host_count && h->search_seq) ? h->host_count[8 * ls + i] : 0;
     if (n_queries) *n_queries = h->search_seq ? h->count_nq[ls] : 0;
     return RADAD_OK;

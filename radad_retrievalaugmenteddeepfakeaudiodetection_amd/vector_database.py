@@ -74,9 +74,10 @@ def write_faiss_flat(path: str, rows: np.ndarray, metric: str):
 
 def knn_options_from_config(config):
     """the optional scan knobs, read the way the reference reads its own optional ones (getattr with a default,
-    vector_database.py:43,67,80): knn_hi_plane, knn_centre, knn_smallq_hi, knn_wide_min_q; absent / None = the library's default"""
+    vector_database.py:43,67,80): knn_hi_plane, knn_centre, knn_smallq_hi, knn_wide_min_q, knn_dense; absent / None = the library's default"""
     opts = dict(hi_plane=getattr(config, "knn_hi_plane", None), centre=getattr(config, "knn_centre", None),
-                smallq_hi=getattr(config, "knn_smallq_hi", None), wide_min_q=getattr(config, "knn_wide_min_q", None))
+                smallq_hi=getattr(config, "knn_smallq_hi", None), wide_min_q=getattr(config, "knn_wide_min_q", None),
+                dense=getattr(config, "knn_dense", None))
     return {k: v for k, v in opts.items() if v is not None}
 
 
@@ -86,8 +87,8 @@ class HipFlatIndex:
     is_trained = True   # flat indexes need no training (vector_database.py:124)
 
     def __init__(self, d: int, metric: int, device: int = 0, id_base: int = 0, store_f16: bool = False, hi_plane=None, centre=None,
-                 smallq_hi=None, wide_min_q=None):
-        """hi_plane / centre / smallq_hi / wide_min_q: kernel choices of the handle (radad_knn_set_option; None = the library's
+                 smallq_hi=None, wide_min_q=None, dense=None):
+        """hi_plane / centre / smallq_hi / wide_min_q / dense: kernel choices of the handle (radad_knn_set_option; None = the library's
         default).  They change speed, never results: A/B measurements and the parity tests select kernels through them."""
         self._lib = _lib.load()
         self.d = int(d)
@@ -99,9 +100,9 @@ class HipFlatIndex:
         _lib.check(self._lib.radad_knn_create_ex(self.d, self.metric, _lib.STORE_F16 if self.store_f16 else _lib.STORE_F32,
                                                  self.device, self.id_base, C.byref(h)), "radad_knn_create")
         self._h = h
-        self.options = dict(hi_plane=hi_plane, centre=centre, smallq_hi=smallq_hi, wide_min_q=wide_min_q)
+        self.options = dict(hi_plane=hi_plane, centre=centre, smallq_hi=smallq_hi, wide_min_q=wide_min_q, dense=dense)
         for opt, val in ((_lib.KNN_OPT_HI_PLANE, hi_plane), (_lib.KNN_OPT_CENTRE, centre), (_lib.KNN_OPT_SMALLQ_HI, smallq_hi),
-                         (_lib.KNN_OPT_WIDE_MIN_Q, wide_min_q)):
+                         (_lib.KNN_OPT_WIDE_MIN_Q, wide_min_q), (_lib.KNN_OPT_DENSE, dense)):
             if val is not None:
                 _lib.check(self._lib.radad_knn_set_option(self._h, opt, int(val)), "radad_knn_set_option")
 
@@ -265,14 +266,14 @@ class HipFlatIndex:
         _lib.check(self._lib.radad_knn_last_scan_launches(self._h, C.byref(nl)))
         return {"query_tiles": a.value, "db_splits": b.value, "block_threads": c.value, "rechecked_queries": st[0],
                 "scan_launches": nl.value,
-                "scan_kind": ("f32_tile", "hi_tile", "f32_smallq", "hi_smallq", "f16_tile")[kind.value],
+                "scan_kind": ("f32_tile", "hi_tile", "f32_smallq", "hi_smallq", "f16_tile", "f32_dense")[kind.value],
                 "certificate": {"queries": nq.value, "rejected": st[0], "candidates_rescored": st[1],
                                 "rejected_buffer_full": st[2], "rejected_list_used_up": st[3],
                                 "rejected_floor_above_threshold": st[4], "rejected_scan_dropped": st[5]}}
 
-    def profile(self, enable: bool = True):
-        """record HIP events around every scan-kernel launch (ring of 64)"""
-        _lib.check(self._lib.radad_knn_profile(self._h, 1 if enable else 0), "radad_knn_profile")
+    def profile(self, enable: bool = True, every: int = 1):
+        """record HIP events around every scan-kernel launch (ring of 64) of every `every`-th search"""
+        _lib.check(self._lib.radad_knn_profile(self._h, max(1, int(every)) if enable else 0), "radad_knn_profile")
 
     def profile_read(self):
         """scan-kernel durations in ms (synchronises on the recorded events)"""
@@ -314,7 +315,8 @@ class HipIVFFlatIndex:
     (vector_database.py:65-70,124-128,138,174-181; pipeline.py:503): d, nlist, nprobe, is_trained, ntotal, train, add,
     search, reconstruct."""
 
-    def __init__(self, d: int, nlist: int, device: int = 0, niter: int = 10):
+    def __init__(self, d: int, nlist: int, device: int = 0, niter: int = 10, hi_scan=None):
+        """hi_scan: 0 keeps the list scans on the fp32 rows (radad_ivf_set_option; None = the library's default, the certified f16 scan)"""
         self._lib = _lib.load()
         self.d, self.nlist, self.device, self.niter = int(d), int(nlist), int(device), int(niter)
         self.nprobe = 1                      # faiss default; the reference sets it from config.vector_db_nprobe (:177)
@@ -324,6 +326,8 @@ class HipIVFFlatIndex:
         h = C.c_void_p()
         _lib.check(self._lib.radad_ivf_create(self.d, self.nlist, self.device, C.byref(h)), "radad_ivf_create")
         self._h = h
+        if hi_scan is not None:
+            _lib.check(self._lib.radad_ivf_set_option(self._h, _lib.IVF_OPT_HI_SCAN, int(hi_scan)), "radad_ivf_set_option")
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -417,6 +421,13 @@ class HipIVFFlatIndex:
     def search(self, x, k: int):
         D, I = self.search_device(x, k)
         return D.cpu().numpy(), I.cpu().numpy()
+
+    def last_search_info(self) -> dict:
+        """{"scan": "f32_lists" | "hi_lists" | "exact_flat", "rejected": queries the f16 scan's certificate handed to the fp32 pass}
+        of the most recent search (synchronises with it)"""
+        kind, rej = C.c_int(), C.c_int()
+        _lib.check(self._lib.radad_ivf_last_search_info(self._h, C.byref(kind), C.byref(rej)), "radad_ivf_last_search_info")
+        return {"scan": _lib.IVF_SCAN_KINDS[kind.value], "rejected": rej.value}
 
     SNAPSHOT_CHUNK = 1 << 18
 

@@ -118,3 +118,52 @@ def test_ivf_large_k_is_answered_by_the_exact_scan(gpu, k):
     np.testing.assert_allclose(D, od, rtol=1e-5, atol=1e-5)
     with pytest.raises(ValueError):
         idx.search(q, 129)
+
+
+@pytest.mark.parametrize("hi_scan,nq", [(1, 1), (1, 40), (1, 700), (0, 40), (2, 40), (2, 3)])
+def test_ivf_list_scan_variants_agree_with_the_oracle(gpu, hi_scan, nq):
+    """the certified f16 list scan (default), the fp32 list scan alone (hi_scan 0), and the fp32 pass behind the f16 scan when the
+    certificate rejects (hi_scan 2 declares every query rejected): the same float64 oracle restricted to the probed lists; one query
+    (lists split over several workgroups), a few tasks per list, and lists probed by more than 16 queries (several tasks per list)"""
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    n, dim, nlist, k, nprobe = 40000, 256, 96, 15, 12
+    db = _clustered(n, dim, 60, 5201)
+    q = _clustered(nq, dim, 60, 5203)
+    idx = R.HipIVFFlatIndex(dim, nlist, gpu.index or 0, hi_scan=hi_scan)
+    idx.train(db[:10000])
+    idx.add(db)
+    idx.nprobe = nprobe
+    D, I = idx.search(q, k)
+    info = idx.last_search_info()
+    assert info["scan"] == ("f32_lists" if hi_scan == 0 else "hi_lists"), info
+    if hi_scan == 2:
+        assert info["rejected"] == nq, info
+    elif hi_scan == 1:
+        assert info["rejected"] <= max(1, nq // 20), info           # the certificate holds on ordinary data
+    od, oi = O.ivf_search(db, idx.assignments(), idx.centroids(), q, k, nprobe)
+    np.testing.assert_array_equal(I, oi)
+    np.testing.assert_allclose(D, od, rtol=1e-6, atol=1e-5)
+    # rows appended afterwards: the list-major plane is gathered again
+    extra = _clustered(3000, dim, 60, 5205)
+    idx.add(extra)
+    db2 = np.concatenate([db, extra])
+    D, I = idx.search(q, k)
+    od, oi = O.ivf_search(db2, idx.assignments(), idx.centroids(), q, k, nprobe)
+    np.testing.assert_array_equal(I, oi)
+
+
+def test_ivf_long_lists_take_several_chunks(gpu):
+    """lists of more than 256 rows (the scan's chunk): the k best of a list are carried from chunk to chunk for the admission bound"""
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    n, dim, nlist, nq, k, nprobe = 30000, 128, 16, 50, 20, 5
+    db = _clustered(n, dim, 8, 5301)
+    q = _clustered(nq, dim, 8, 5303)
+    idx = R.HipIVFFlatIndex(dim, nlist, gpu.index or 0)
+    idx.train(db[:10000])
+    idx.add(db)
+    idx.nprobe = nprobe
+    D, I = idx.search(q, k)
+    assert idx.last_search_info()["scan"] == "hi_lists"
+    od, oi = O.ivf_search(db, idx.assignments(), idx.centroids(), q, k, nprobe)
+    np.testing.assert_array_equal(I, oi)
+    np.testing.assert_allclose(D, od, rtol=1e-6, atol=1e-5)
