@@ -3198,6 +3198,25 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             if (h->ntotal - r1 < span / 4) r1 = h->ntotal;
             // a store the sample's floor alone filters to a third of the buffer (~(k + margin) N / sample rows) is scanned in one go
             if (r0 == 0 && (int64_t)ksel * h->ntotal <= (int64_t)(emit_cap / 3) * s_splits * KW_M) r1 = h->ntotal;
+            // A launch deals whole tiles to its row splits, ceil(tiles / splits) each: what decides its time is that quotient, and a
+            // remainder of a few tiles costs a whole extra tile per workgroup (64 + 260 tiles over 128 splits = 1 + 3 tile times, the last
+            // round of the second launch nearly empty; 68 + 256 tiles = 1 + 2).  When the LAST launch follows this one, up to a quarter
+            // more tiles move into this one if that lowers the sum of the two quotients.  (BASELINE config 2 -- 100 k rows = 64 + 327
+            // tiles -- gains nothing from it: 1 + 3 either way; its scan stays at 0.27 of the MFMA peak, 1 564 tile tasks over 256 CUs.)
+            if (r1 < h->ntotal && (h->ntotal - r1 <= span * 8 || h->ntotal - r1 - span * 8 < span * 2)) {
+                auto tile_time = [&](int64_t rows) {
+                    int gq, gs; int64_t gc;
+                    knn_geometry_wide(rows, nq, &gq, &gs, &gc);
+                    return gc / KW_M;
+                };
+                const int64_t t_this = ceil_div64(r1 - r0, KW_M), t_rest = ceil_div64(h->ntotal - r1, KW_M);
+                int64_t best = tile_time(r1 - r0) + tile_time(h->ntotal - r1), best_s = 0;
+                for (int64_t sft = 1; sft <= std::min<int64_t>(t_this / 4, t_rest - 1); ++sft) {
+                    const int64_t c = tile_time(r1 - r0 + sft * KW_M) + tile_time(h->ntotal - r1 - sft * KW_M);
+                    if (c < best) { best = c; best_s = sft; }
+                }
+                r1 += best_s * KW_M;
+            }
             if (r0 > 0) {
                 KthParams kp;
                 kp.score = ps; kp.cnt = cand_cnt; kp.cap = emit_cap; kp.k = k; kp.eps = eps; kp.floor_io = thr_init; kp.lb_out = nullptr; kp.ak_out = nullptr;
