@@ -2848,6 +2848,7 @@ static int knn_tile_ksplit(radad_knn_t h, int qtiles_grid, int n_splits, int64_t
     const int64_t tiles = ceil_div64(rows, KW_M);
     if (chunk_rows != KW_M || (int64_t)qtiles_grid * n_splits > 128 || h->dim * 2 / 128 < 16) return 1;
     const int64_t need = tiles * qtiles_grid;
+    if ((size_t)need * 2 * 32 * KW_THREADS * sizeof(f32x4) > ((size_t)256 << 20)) return 1;      // (a spread sample over a large store: not worth 0.5 MB per tile)
     if (need > h->kacc_tiles) {
         (void)hipStreamSynchronize(st);
         if (h->kacc) (void)hipFree(h->kacc);
@@ -3154,7 +3155,8 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             sp.n = h->ntotal; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
             sp.chunk_stride = std::max<int64_t>(1, (h->ntotal / KW_M) / s_splits) * KW_M;
             const int sq_grid = sp.n_qtiles <= 8 ? sp.n_qtiles : (sp.n_qtiles + 7) / 8 * 8;
-            sp.ksplit = knn_tile_ksplit(h, sq_grid, sp.n_splits, KW_M, (int64_t)s_splits * KW_M, st);
+            // (the K split's scratch is indexed by row0 / KW_M: the sample's tiles lie anywhere in the store)
+            sp.ksplit = knn_tile_ksplit(h, sq_grid, sp.n_splits, KW_M, h->ntotal, st);
             sp.kacc = h->kacc; sp.kflag = h->kflag;
             const dim3 sg((unsigned)(sq_grid * sp.n_splits * sp.ksplit)), sb(KW_THREADS);
             if (rsc == 0) hipLaunchKernelGGL(k_knn_hi_sample<0>, sg, sb, lds, st, sp);
@@ -3177,7 +3179,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             rp.loose_floor = (r0 == 0 && r1 == h->ntotal && s_splits < KW_SAMPLE_SPLITS) ? 1 : 0;      // one launch behind a small sample
             int gq, gs; int64_t gc;
             knn_geometry_wide(rp.n, nq, &gq, &gs, &gc);
-            rp.n_splits = gs; rp.chunk_rows = gc;
+            rp.n_splits = gs; rp.chunk_rows = gc; rp.chunk_stride = gc;
             h->last_splits = gs;
             const int gq_grid = gq <= 8 ? gq : (gq + 7) / 8 * 8;                      // (more than 8 query tiles: whole groups of 8, see the kernel)
             rp.ksplit = knn_tile_ksplit(h, gq_grid, gs, gc, rp.n, st);

@@ -291,3 +291,80 @@ def test_refine_forms_agree(gpu, metric):
     else:
         _, oi = O.knn(stored, q, k, "L2")
     np.testing.assert_array_equal(I1, oi)
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "L2"])
+def test_small_batches_on_adversarial_stores(gpu, metric):
+    """the same adversarial store through the small-batch chain (<= 16 queries: f16 streaming scan with 16-entry lists per workgroup,
+    k_refine_small with 8 workgroups per query): 100 adjacent exact duplicates use a workgroup's list up, 700 near-ties exceed the
+    candidate buffer -- both queries must come back from the exact kernel with the brute-force result, the others certified; and a
+    query with 24 near-ties around rank k is certified without it"""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+    n, dim, k = 50000, 64, 15
+    db = synth.rows(0, n, dim, 7101)
+    qall = synth.rows(0, 80, dim, 7102)
+    near = qall[33] + np.float32(0.05) * synth.rows(1, 1, dim, 7103)[0]
+    for t in range(700):
+        row = near.copy()
+        row[t % dim] += np.float32(3e-4 * ((t * 7) % 11 - 5))
+        db[(t * 67 + 11) % n] = row
+    db[20000:20100] = qall[7] + np.float32(0.05) * synth.rows(0, 1, dim, 7103)[0]
+    base = qall[5] + np.float32(0.08) * synth.rows(99, 1, dim, 7003)[0]
+    for t in range(24):
+        row = base.copy()
+        row[t % dim] += np.float32(1e-6 * (t + 1))
+        db[2000 + 1531 * t] = row
+    idx = _index(metric, dim)
+    idx.add(db)
+    stored = _stored(idx, n, gpu)
+    for sel in ([7], [33], [5], [7, 33, 5, 0, 1, 2, 3, 4, 6, 8, 9, 10, 11], list(range(16))):
+        q = qall[sel]
+        D, I = idx.search(q, k)
+        info = idx.last_launch()
+        assert info["scan_kind"] == "hi_smallq", info
+        if metric == "COSINE":
+            qt = torch.from_numpy(q).to(gpu); qo = torch.empty_like(qt)
+            _lib.check(_lib.load().radad_rownorm(qt.data_ptr(), qo.data_ptr(), len(sel), dim, 0, _lib.stream_ptr(gpu)))
+            od, oi = O.knn(stored, qo.cpu().numpy(), k, "IP")
+        else:
+            od, oi = O.knn(stored, q, k, "L2")
+        np.testing.assert_array_equal(I, oi)
+        np.testing.assert_allclose(D, od, rtol=1e-6, atol=1e-6)
+        rej = info["certificate"]["rejected"]
+        hard = len({7, 33} & set(sel))
+        assert hard <= rej <= hard + 1, (sel, info)
+        if 7 in sel:
+            assert list(I[sel.index(7)]) == list(range(20000, 20000 + k))       # exact ties: lower ids first
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "L2", "IP"])
+@pytest.mark.parametrize("n,dim", [(4096, 512), (6000, 64), (777, 128)])
+def test_small_stores_score_densely(gpu, metric, n, dim):
+    """fp32 stores of a few thousand rows (the IVF index's centroids; a small database): every score written out by k_knn_dense, the
+    certified select on them -- same ids as the float64 brute force and as the register-list kernels (dense=0), for one query, a
+    ragged batch and k up to 100; a near-tie pair within 1e-7 is ordered by the float64 re-rank"""
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    m = {"L2": _lib.METRIC_L2, "IP": _lib.METRIC_IP, "COSINE": _lib.METRIC_COSINE}[metric]
+    db = synth.rows(0, n, dim, 7301)
+    q = synth.rows(0, 300, dim, 7302)
+    db[11] = q[3] + np.float32(0.02) * synth.rows(0, 1, dim, 7303)[0]
+    db[500] = db[11]
+    db[500, 0] += np.float32(1e-6)
+    a = HipFlatIndex(dim, m, 0)
+    a.add(db)
+    b = HipFlatIndex(dim, m, 0, dense=0)
+    b.add(db)
+    stored = _stored(a, n, gpu)
+    for nq, k in ((1, 15), (5, 32), (300, 10), (77, 100)):
+        D, I = a.search(q[:nq], k)
+        assert a.last_launch()["scan_kind"] == "f32_dense", a.last_launch()
+        Db, Ib = b.search(q[:nq], k)
+        assert b.last_launch()["scan_kind"] != "f32_dense"
+        np.testing.assert_array_equal(I, Ib)
+        if metric == "COSINE":
+            od, oi = O.knn(stored, _unit(q[:nq]), k, "IP")
+        else:
+            od, oi = O.knn(stored, q[:nq], k, metric)
+        np.testing.assert_array_equal(I, oi)
+        assert a.last_launch()["certificate"]["rejected"] == 0
