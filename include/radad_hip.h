@@ -10,8 +10,10 @@
  *   - every function returns 0 on success and a negative RADAD_E* code on failure; the message for the
  *     calling thread is available from radad_last_error().
  *   - handles are opaque.  A handle may be searched/reconstructed from several threads (host calls are serialised by a
- *     mutex, the device work of consecutive searches by an event: they share one workspace); add/load/destroy must
- *     not race with anything else.
+ *     mutex, the device work of consecutive searches by stream order -- a search on ANOTHER stream than the previous one first
+ *     records an event behind that stream's work and waits for it: they share one workspace; a stream a handle was last
+ *     searched on should therefore outlive the handle's next search, else that search synchronises the device); add/load/destroy
+ *     must not race with anything else.
  *   - "without synchronising" has one exception per store: the FIRST large-batch search after the store was created, grown
  *     past its capacity, or re-decided (radad_knn_plane_rebuilds) builds the f16 plane inside the call -- hipDeviceSynchronize,
  *     hipMalloc of 2 bytes per element, one small read-back -- i.e. it stalls every stream of the device once (0.84 ms of
@@ -123,8 +125,8 @@ int radad_knn_search(radad_knn_t h, const float* q_dev, int64_t nq, int k, float
  * k <= 128 ids and order are therefore those of an exact float64 brute force, ties to the lower id, and out_dist is the
  * correctly rounded distance; for larger k the k + 6 best scan candidates are re-ranked without a certificate.  Sharded
  * searches merge on these keys (radad_topk_merge_f64) so that no cross-shard pair is decided by fp32 rounding.
- * A handle may be searched from several threads and streams: calls are serialised by a mutex and each search's device
- * work waits (event) for the previous one's, since they share the handle's workspace. */
+ * A handle may be searched from several threads and streams: calls are serialised by a mutex and a search enqueued on another
+ * stream than the previous one waits (event) for that one's device work, since they share the handle's workspace. */
 int radad_knn_search_f64(radad_knn_t h, const float* q_dev, int64_t nq, int k, float* out_dist_dev,
                          int64_t* out_idx_dev, double* out_key_dev, void* stream);
 /* same with a choice of query type: RADAD_Q_BF16 = bfloat16 queries [nq, dim] (BASELINE config 5: bf16 embeddings,
@@ -350,6 +352,10 @@ int radad_embed_forward_ex(radad_embed_t h, const float* wave_dev, const int64_t
  * segments for buffer and grid sizes. */
 int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_dev, int64_t n_clips,
                             int64_t n_samples_total, void* out_dev, int out_dtype, void* stream);
+/* 16-bit PCM (what audio files hold) -> the float32 samples the reference's loader produces (pipeline.py / dataset.py: librosa.load,
+ * i.e. sample / 32768, exact in fp32), on the device: upload the PCM, convert here, hand the result to radad_embed_forward* --
+ * half the bytes over PCIe.  out_dev may not alias pcm_dev. */
+int radad_pcm16_to_f32(const int16_t* pcm_dev, float* out_dev, int64_t n, int device, void* stream);
 /* The device-resident offsets cannot be validated by the host without a synchronisation (the host path of
  * radad_embed_forward rejects bad offsets up front, as segmenter.py:18-19 raises on bad input).  The plan kernel therefore
  * REPAIRS them -- every clip is clamped into [0, n_samples_total], a clip that ends before it starts becomes empty, the

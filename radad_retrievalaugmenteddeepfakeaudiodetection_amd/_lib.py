@@ -127,6 +127,7 @@ SIGNATURES = {
     "radad_embed_forward": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, C.c_int64, C.c_void_p, C.c_void_p]),
     "radad_embed_forward_ex": (C.c_int, [C.c_void_p, C.c_void_p, c_i64p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
     "radad_embed_forward_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int, C.c_void_p]),
+    "radad_pcm16_to_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     "radad_embed_plan_flags": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_embed_plan_flags_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "radad_embed_last_logmel_kind": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),

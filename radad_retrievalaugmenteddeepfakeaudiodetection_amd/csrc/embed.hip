@@ -1605,6 +1605,32 @@ int radad_embed_forward(radad_embed_t h, const float* wave_dev, const int64_t* c
     return radad_embed_forward_ex(h, wave_dev, clip_offsets_host, n_clips, out_dev, RADAD_OUT_F32, stream);
 }
 
+// 16-bit PCM -> float32 as the reference's loader hands it over (librosa / soundfile: sample / 32768, exact in fp32): audio files
+// are int16, so a deployment that uploads the PCM and converts here moves half the bytes over PCIe (bench.py's pcie_inclusive leg)
+__global__ __launch_bounds__(256) void k_pcm16_to_f32(const short* __restrict__ in, float* __restrict__ out, int64_t n) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const s16x8 v = *reinterpret_cast<const s16x8*>(in + i);
+        f32x4 a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+        a *= 0x1p-15f; b *= 0x1p-15f;
+        *reinterpret_cast<f32x4*>(out + i) = a;
+        *reinterpret_cast<f32x4*>(out + i + 4) = b;
+    } else {
+        for (int64_t j = i; j < n && j < i + 8; ++j) out[j] = (float)in[j] * 0x1p-15f;
+    }
+}
+
+int radad_pcm16_to_f32(const int16_t* pcm_dev, float* out_dev, int64_t n, int device, void* stream) {
+    RADAD_REQUIRE(n >= 0, "radad_pcm16_to_f32: negative length");
+    if (n == 0) return RADAD_OK;
+    RADAD_REQUIRE(pcm_dev && out_dev, "radad_pcm16_to_f32: NULL buffer");
+    DeviceGuard g(device);
+    hipLaunchKernelGGL(k_pcm16_to_f32, dim3((unsigned)ceil_div64(n, 2048)), dim3(256), 0, (hipStream_t)stream, (const short*)pcm_dev, out_dev, n);
+    RADAD_HIP_CHECK(hipGetLastError());
+    return RADAD_OK;
+}
+
 int radad_embed_forward_dev(radad_embed_t h, const float* wave_dev, const int64_t* clip_offsets_dev, int64_t n_clips,
                             int64_t n_samples_total, void* out_dev, int out_dtype, void* stream) {
     RADAD_REQUIRE(h, "NULL handle");

@@ -2331,8 +2331,8 @@ struct radad_knn_s {
     int* host_count_dev = nullptr;   // the same memory as the device sees it
     hipEvent_t ev_done = nullptr;
     hipEvent_t ev_begun = nullptr;      // end of radad_knn_search_begin's device work: _finish waits for it (it may run on another stream)
-    bool done_recorded = false;
-    hipStream_t last_stream = nullptr;   // where the last search was enqueued (owned_serial handles synchronise on it for the statistics)
+    bool have_last = false;
+    hipStream_t last_stream = nullptr;   // where the last search was enqueued (the next one on ANOTHER stream orders itself behind it; the statistics calls synchronise on it)
     int64_t count_nq[2] = {0, 0};    // batch size of the search a slot belongs to
     uint64_t search_seq = 0;     // certified searches so far
     int hi_skip = 0;             // searches left on the fp32 kernels after the certified scan rejected too many queries
@@ -2886,16 +2886,23 @@ static int knn_tile_ksplit(radad_knn_t h, int qtiles_grid, int n_splits, int64_t
 
 // the most recent search's device work is complete (its statistics are in the pinned host copy)
 static hipError_t knn_wait_last_search(radad_knn_t h) {
-    if (h->done_recorded) return hipEventSynchronize(h->ev_done);
-    if (h->owned_serial) return hipStreamSynchronize(h->last_stream);
-    return hipSuccess;
+    if (!h->have_last) return hipSuccess;
+    if (hipStreamSynchronize(h->last_stream) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();                            // (the stream is gone: everything on the device, then)
+    return hipDeviceSynchronize();
 }
 
 static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64_t nq, int k, int margin, float* lb_out, hipStream_t st,
                              SearchCtx* ctx) {
     // one workspace per handle: a search on another stream waits for the previous one (threads are serialised by h->mu,
     // the device work by this event)
-    if (h->done_recorded) RADAD_HIP_CHECK(hipStreamWaitEvent(st, h->ev_done, 0));
+    // (searches share the handle's workspace.  On ONE stream they are ordered anyway; a search on another stream than the last one
+    // first records an event behind whatever that stream holds and waits for it -- recording one behind EVERY search, as until round 4,
+    // held the kernel after each search back ~6 us, 5 % of an online search)
+    if (h->have_last && !h->owned_serial && st != h->last_stream) {
+        if (hipEventRecord(h->ev_done, h->last_stream) == hipSuccess) RADAD_HIP_CHECK(hipStreamWaitEvent(st, h->ev_done, 0));
+        else { (void)hipGetLastError(); RADAD_HIP_CHECK(hipDeviceSynchronize()); }      // (that stream no longer exists)
+    }
 
     h->prof.next_search();
     const bool cert = k <= KNN_CERT_MAX_K;      // beyond: legacy k + margin candidates, no certificate
@@ -3434,11 +3441,8 @@ static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* glo
         h->count_nq[c.cslot] = nq;                                     // (k_exact_scan writes the counters and its stamp to the pinned host copy)
         ++h->search_seq;
     }
-    if (!h->owned_serial) {
-        RADAD_HIP_CHECK(hipEventRecord(h->ev_done, st));
-        h->done_recorded = true;
-    }
     h->last_stream = st;
+    h->have_last = true;
     return RADAD_OK;
 }
 

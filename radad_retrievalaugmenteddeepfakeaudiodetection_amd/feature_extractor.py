@@ -125,13 +125,24 @@ class MelProjectionFeatureExtractor:
 
     # ---- batched device path --------------------------------------------------------------------------
     def embed_clips(self, wave, clip_offsets, out_dtype=None):
-        """wave: 1-D float32 CUDA tensor holding the clips back to back; clip_offsets: B+1 ints, either on the host
+        """wave: 1-D float32 CUDA tensor holding the clips back to back (or int16 PCM: converted on the device as librosa.load would,
+        sample / 32768); clip_offsets: B+1 ints, either on the host
         (sequence / numpy) or an int64 CUDA tensor -- then the segment plan (segmenter.py:25-39) is built on the device and
         nothing synchronises with the host.  out_dtype: torch.float32 (default) or torch.bfloat16 (BASELINE config 5).
         Returns the clip embeddings [B, sum(levels)*F] (segment -> embed of pipeline.py:392-414)."""
         import torch
         _lib.require_cuda(wave, "wave")
-        if wave.dtype != torch.float32 or not wave.is_contiguous():
+        if wave.dtype == torch.int16:
+            # 16-bit PCM as the audio files hold it: sample / 32768 on the device (what librosa.load returns), into a buffer this
+            # extractor keeps -- an upload of the PCM moves half the bytes of the float samples over PCIe
+            pcm = wave.contiguous()
+            if getattr(self, "_pcm_f32", None) is None or self._pcm_f32.numel() < pcm.numel() or self._pcm_f32.device != pcm.device:
+                self._pcm_f32 = torch.empty(pcm.numel(), device=pcm.device, dtype=torch.float32)
+            wave = self._pcm_f32[:pcm.numel()]
+            with torch.cuda.device(pcm.device):
+                _lib.check(self._lib.radad_pcm16_to_f32(pcm.data_ptr(), wave.data_ptr(), pcm.numel(), pcm.device.index or 0,
+                                                        _lib.stream_ptr(pcm.device)), "radad_pcm16_to_f32")
+        elif wave.dtype != torch.float32 or not wave.is_contiguous():
             wave = wave.contiguous().float()
         out_dtype = out_dtype or torch.float32
         if out_dtype not in (torch.float32, torch.bfloat16):

@@ -219,3 +219,22 @@ def test_synth_device_equals_host(gpu):
     a = torch.empty((5, 64000), device=gpu)
     _lib.check(lib.radad_synth_audio(a.data_ptr(), 7, 5, 64000, 1234, gpu.index or 0, _lib.stream_ptr(gpu)))
     np.testing.assert_array_equal(a.cpu().numpy(), synth.audio(7, 5, 64000, 1234))
+
+
+def test_int16_pcm_input_is_the_loaders_float(gpu):
+    """embed_clips on 16-bit PCM == embed_clips on sample / 32768 in float32 (what librosa.load / soundfile hand the reference),
+    bit for bit: the conversion is exact, the rest is the same kernels; odd lengths and an unaligned start take the scalar tail"""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import _lib
+    fe, _ = _fe(gpu, feature_dim=128, tpp_levels=[1, 2])
+    rng = np.random.default_rng(5)
+    lens = [48000, 33001, 64000, 16007]
+    pcm = torch.from_numpy(rng.integers(-32768, 32767, size=sum(lens), endpoint=True).astype(np.int16)).to(gpu)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    a = fe.embed_clips(pcm, offs)
+    b = fe.embed_clips(pcm.float() / 32768.0, offs)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    lib = _lib.load()
+    out = torch.empty(1001, device=gpu)
+    _lib.check(lib.radad_pcm16_to_f32(pcm.data_ptr() + 2, out.data_ptr(), 1001, gpu.index or 0, _lib.stream_ptr(gpu)))      # unaligned source
+    assert torch.equal(out, pcm[1:1002].float() / 32768.0)

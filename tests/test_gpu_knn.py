@@ -612,3 +612,36 @@ def test_large_k_stays_on_the_certified_f16_scan(gpu, metric, k):
     assert O.rank_gaps(od).min() > 0
     np.testing.assert_array_equal(I, oi)
     np.testing.assert_allclose(D, od, rtol=1e-5, atol=1e-5)
+
+
+def test_searches_alternating_between_streams_share_the_workspace_safely(gpu):
+    """one handle, two streams, searches enqueued alternately without any host synchronisation in between: they share the handle's
+    workspace, so a search on another stream than the previous one must wait for it (an event recorded behind the previous stream
+    when the next search arrives; none at all on one stream).  Results == the same searches done one at a time; flat and IVF."""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    n, dim, k = 60000, 128, 10
+    db = torch.from_numpy(synth.rows(0, n, dim, 9101)).to(gpu)
+    qs = [torch.from_numpy(synth.rows(0, nq, dim, 9110 + i)).to(gpu) for i, nq in enumerate((300, 1, 700, 16, 40, 1000))]
+    flat = HipFlatIndex(dim, _lib.METRIC_L2, 0)
+    flat.add_device(db)
+    ivf = R.HipIVFFlatIndex(dim, 64, 0)
+    ivf.train(db[:10000].cpu().numpy())
+    ivf.add(db.cpu().numpy())
+    ivf.nprobe = 8
+    for index in (flat, ivf):
+        want = []
+        for q in qs:
+            D, I = index.search_device(q, k)
+            want.append((D.clone(), I.clone()))
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=gpu), torch.cuda.Stream(device=gpu)]
+        for rep in range(3):
+            got = []
+            for i, q in enumerate(qs):
+                with torch.cuda.stream(streams[(i + rep) & 1]):
+                    got.append(index.search_device(q, k))
+            torch.cuda.synchronize()
+            for (D, I), (Dw, Iw) in zip(got, want):
+                assert torch.equal(I, Iw) and torch.equal(D, Dw)
