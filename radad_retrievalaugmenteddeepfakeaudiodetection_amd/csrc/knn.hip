@@ -3025,7 +3025,10 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
                           : f16_tile ? RADAD_SCAN_F16_TILE : RADAD_SCAN_F32_TILE;
     const int plen = use_hi ? emit_cap : dense ? dense_plen : ksel_sq;   // entries of a partial list / of the candidate buffer
     const int n_parts = (use_hi || dense) ? 1 : n_splits;
-    const int cap = cert ? std::max(k + KNN_CERT_EXTRA, KNN_CERT_CAP) : ksel;
+    // (dense: eps of exact fp32 products is ~1e-6 of |q||y| -- hardly a row beyond the k best is within 2 eps; k + 32 candidates keep
+    // the re-rank's workgroup at 34 KB of LDS for 4096 staged scores, four per CU instead of three: the IVF coarse step's 1024
+    // workgroups in one round.  More near-ties than that reject the query: exact kernel.)
+    const int cap = cert ? (dense ? k + KNN_CERT_EXTRA : std::max(k + KNN_CERT_EXTRA, KNN_CERT_CAP)) : ksel;
     const int xgroup = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(64 * 1024) / ((size_t)h->dim * 4)));
 
     // ---- workspace: qf (decoded bf16) | qn (normalised) | qh (f16 queries) | qscale | qconst | eps | thr_init | cand_cnt |
