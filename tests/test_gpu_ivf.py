@@ -167,3 +167,34 @@ def test_ivf_long_lists_take_several_chunks(gpu):
     od, oi = O.ivf_search(db, idx.assignments(), idx.centroids(), q, k, nprobe)
     np.testing.assert_array_equal(I, oi)
     np.testing.assert_allclose(D, od, rtol=1e-6, atol=1e-5)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_ivf_fuzz_against_the_oracle(gpu, seed):
+    """bounded random sweep over the IVF search: dims with and without an f16 plane (dim % 64), one query to a few thousand, k from 1 to
+    26, nprobe from 1 to every list, more lists than rows per list (empty lists), skewed lists; ids == the float64 oracle restricted to
+    the probed lists, every time"""
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    rng = np.random.default_rng(100 + seed)
+    for case in range(6):
+        dim = int(rng.choice([64, 96, 128, 320, 512]))
+        nlist = int(rng.choice([16, 50, 128, 300]))
+        n = int(rng.choice([3000, 20000, 45000]))
+        nq = int(rng.choice([1, 2, 16, 17, 100, 1500]))
+        k = int(rng.choice([1, 5, 15, 26]))
+        nprobe = int(rng.choice([1, 3, 8, nlist]))
+        n_clusters = int(rng.choice([3, 40, 400]))
+        db = _clustered(n, dim, n_clusters, 6000 + 10 * seed + case)
+        q = _clustered(nq, dim, n_clusters, 6500 + 10 * seed + case)
+        idx = R.HipIVFFlatIndex(dim, nlist, gpu.index or 0, niter=int(rng.choice([0, 3])))
+        idx.train(db[: min(n, 8000)])
+        idx.add(db)
+        idx.nprobe = nprobe
+        D, I = idx.search(q, k)
+        info = idx.last_search_info()
+        what = dict(seed=seed, case=case, dim=dim, nlist=nlist, n=n, nq=nq, k=k, nprobe=nprobe, n_clusters=n_clusters, info=info)
+        assert info["scan"] == ("hi_lists" if dim % 64 == 0 else "f32_lists"), what
+        od, oi = O.ivf_search(db, idx.assignments(), idx.centroids(), q, k, min(nprobe, nlist))
+        np.testing.assert_array_equal(I, oi, err_msg=str(what))
+        fin = np.isfinite(od)
+        np.testing.assert_allclose(D[fin], od[fin], rtol=1e-6, atol=1e-5, err_msg=str(what))
