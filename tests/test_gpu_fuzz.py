@@ -210,3 +210,62 @@ def test_fuzz_embed_shared_frames(gpu, seed, kernel):
         err = float(np.abs(emb.cpu().numpy() - ref).max())
         assert emb.shape == ref.shape and err < 1e-4, dict(what, err=err)
         assert torch.equal(emb, emb_dev), what
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_fuzz_small_batches_and_small_stores(gpu, knn_oracle_lib, seed):
+    """the chains round 4 added, under random shapes: batches of 1..16 queries (streaming scans with 16- or 32-entry lists,
+    k_refine_small with 8 workgroups per query, the K-split form on wide rows) and stores of a few thousand rows (k_knn_dense), all
+    metrics, embedding-like rows with a common component or not, rows of many magnitudes; ids and float64 keys against the C oracle
+    on the rows AS STORED."""
+    import torch
+    from conftest import c_knn
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(seed)
+
+    def dev_rows(row0, n, dim, sd):
+        t = torch.empty((n, dim), device=gpu, dtype=torch.float32)
+        _lib.check(lib.radad_synth_rows(t.data_ptr(), row0, n, dim, sd, gpu.index or 0, _lib.stream_ptr(gpu)))
+        return t
+
+    for case in range(8):
+        metric = ["L2", "IP", "COSINE"][rng.integers(3)]
+        n, dim = [(3000, 256), (6144, 64), (16384, 128), (20000, 512), (70000, 128), (25423, 1024), (9000, 2048)][rng.integers(7)]
+        nq = int(rng.choice([1, 2, 7, 16] if n > 6144 else [1, 16, 40, 700]))
+        k = int(rng.choice([1, 10, 15, 16, 26]))
+        common = bool(rng.integers(2))
+        ragged_scale = bool(rng.integers(3) == 0) and metric != "COSINE"
+        rows = dev_rows(0, n, dim, 30000 + 100 * seed + case)
+        q = dev_rows(0, nq, dim, 31000 + 100 * seed + case)
+        if common:
+            base = dev_rows(0, 1, dim, 32000 + case).abs() + 0.5
+            rows = base + 0.3 * rows
+            q = base + 0.3 * q
+        if ragged_scale:
+            rows *= torch.exp2(torch.arange(n, device=gpu) % 19 - 9).float()[:, None]
+        jj = torch.arange(nq, device=gpu)
+        rows[(jj * 131 + 7) % n] = q + 0.03 * dev_rows(0, nq, dim, 33000 + case)
+        m = {"L2": _lib.METRIC_L2, "IP": _lib.METRIC_IP, "COSINE": _lib.METRIC_COSINE}[metric]
+        idx = HipFlatIndex(dim, m, gpu.index or 0)
+        idx.add_device(rows)
+        D, I, K64 = idx.search_device(q, k, return_f64=True)
+        info = idx.last_launch()
+        what = dict(seed=seed, case=case, metric=metric, dim=dim, n=n, nq=nq, k=k, common=common, ragged_scale=ragged_scale, info=info,
+                    plane=idx.plane_info())
+        if n <= 6144:
+            assert info["scan_kind"] == "f32_dense", what
+        elif n >= 16384 and dim % 64 == 0:
+            assert info["scan_kind"] == "hi_smallq", what
+        stored = idx.reconstruct_batch(torch.arange(n, device=gpu)).cpu().numpy()
+        qs = q.contiguous()
+        if metric == "COSINE":
+            qn = torch.empty_like(qs)
+            _lib.check(lib.radad_rownorm(qs.data_ptr(), qn.data_ptr(), qs.shape[0], dim, gpu.index or 0, _lib.stream_ptr(gpu)))
+            qs = qn
+        sel = np.arange(nq)[:24]
+        od, oi = c_knn(knn_oracle_lib, stored, qs[:24].cpu().numpy(), k, "L2" if metric == "L2" else "IP")
+        if O.rank_gaps(od).min() > 0:
+            assert np.array_equal(I[sel].cpu().numpy(), oi), what
+        np.testing.assert_allclose(K64[sel].cpu().numpy(), od, rtol=1e-9, atol=1e-9, err_msg=str(what))
+        del idx, rows, stored
