@@ -3107,7 +3107,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         hp.zero_flags = cert ? cand_cnt : nullptr; hp.zero_counters = cert ? flag_count : nullptr;
         hp.mu = mu; hp.mu_norm = mu ? h->mu_norm : 0.f; hp.mu_sq = mu ? h->mu_sq : 0.f; hp.biased = (biased || (f16_tile && l2)) ? 1 : 0;
         hp.bias_out = nullptr; hp.qconst_out = biased ? qconst : nullptr;
-        hipLaunchKernelGGL(k_hi_rows, dim3(rgrid), dim3(256), 0, st, hp);
+        launch_hi_rows(hp, st);
     }
     if (h->metric == RADAD_METRIC_COSINE) q_use = (const float*)(ws + o_qn);
     RADAD_HIP_CHECK(hipGetLastError());
