@@ -124,6 +124,27 @@ def main():
                     help="bf16 = embeddings emitted and searched as bfloat16 (BASELINE config 5); NOT the headline configuration")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started bare as `python bench.py --gpus N`: become N ranks.  The parent only COUNTS devices (torch.cuda.device_count() does
+        # not initialise the GPU on this image), spawns `python -m torch.distributed.run` as a CHILD process (nothing that has touched
+        # the GPU is ever exec'd), lets rank 0's JSON line through on the inherited stdout and exits with the launcher's status.
+        # Fewer than N devices is an error, never a silent one-rank run -- unless RADAD_BENCH_REHEARSE=1 (all ranks on cuda:0,
+        # gloo collectives: the N-rank code path on a one-GPU box, never a reported number).
+        import socket
+        import subprocess
+        import torch
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus and os.environ.get("RADAD_BENCH_REHEARSE", "0") != "1":
+            print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible; refusing to fall back to fewer ranks "
+                  f"(RADAD_BENCH_REHEARSE=1 rehearses the {args.gpus}-rank path on one GPU over gloo)", file=sys.stderr, flush=True)
+            sys.exit(2)
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -131,7 +152,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr, flush=True)
+        sys.exit(2)
     # RADAD_BENCH_REHEARSE=1: rehearse the N-rank code path on ONE GPU (all ranks on cuda:0, gloo collectives staged
     # through the host).  Never used for a reported number.
     rehearse = os.environ.get("RADAD_BENCH_REHEARSE", "0") == "1"
@@ -530,10 +553,14 @@ def main():
         Q = B                                                           # a replica scans only its own clips
     flops = 2.0 * Q * (hi - lo) * DIM                                   # algorithmic FLOPs of one scan launch
     f16 = args.store_dtype == "f16"
-    esz = 2.0 if f16 else 4.0
-    alg_bytes = esz * (hi - lo) * DIM + 4.0 * Q * DIM + 12.0 * Q * TOP_K
-    achieved = flops / (knn_avg * 1e-3) / 1e12
     wide = launch["block_threads"] == 512                     # the certified f16 scan (knn_hi.inc) took the search
+    # bytes one SEARCH must stream: the operand the scan kernel reads -- the 2-byte f16 plane (or fp16 store) on the certified scan,
+    # the 4-byte rows on the fp32 kernels -- + the queries once + the result lists (SURVEY 8d's s_db * N * D + 4 Q D + 12 Q k with
+    # s_db = what is actually scanned); the fp32 store's own size is a separate key
+    esz = 2.0 if (f16 or wide) else 4.0
+    alg_bytes = esz * (hi - lo) * DIM + 4.0 * Q * DIM + 12.0 * Q * TOP_K
+    store_bytes = (2.0 if f16 else 4.0) * (hi - lo) * DIM
+    achieved = flops / (knn_avg * 1e-3) / 1e12
     if wide:
         kname = "k_knn_hi<0>"
         peak = PEAK_MFMA_F16_TFLOPS
@@ -593,13 +620,20 @@ def main():
         "config": {"workload": wl + f", F=512, levels=[1], cosine top-{TOP_K}, {n_total} x {DIM} {args.store_dtype} store " +
                                     (f"replicated on each of {world} GPUs" if replicate else f"row-sharded over {world} GPU(s)"), "segments_per_gpu": n_segments,
                    "clips_per_gpu": B, "db_rows": n_total, "dim": DIM, "k": TOP_K, "parallelism": (f"replicate{world}" if replicate else f"shard{world}"),
+                   # fixed workload: the clip offsets do not change between steps, so radad_embed_forward reuses the segment plan
+                   # (k_build_plan, 14 us, skipped); --workload ragged rebuilds it on the device every step
+                   "plan_rebuilt_every_step": args.workload != "fixed",
                    "planted_neighbours_found": planted_ok},
         "roofline": {"kernel": kname, "bound": "mfma", "achieved": round(achieved, 2),
                      "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_ms": round(knn_launch_avg, 4), "launches_per_step": n_launch, "scan_ms_per_step": round(knn_avg, 4),
                      "flops_per_launch": flops / n_launch, "algorithmic_bytes_per_launch": alg_bytes / n_launch,
-                     "kernel_operand_bytes_per_launch": (2.0 * (hi - lo) * DIM + 2.0 * Q * DIM + 8.0 * Q * launch["db_splits"] * 16) if wide else alg_bytes,
+                     "algorithmic_bytes_per_search": alg_bytes, "scanned_bytes_per_element": esz,
+                     "store_bytes_resident": store_bytes,
+                     # what the launches of one search read and write, queries re-read once per chunk of the store included
+                     "kernel_operand_bytes_per_launch": ((2.0 * (hi - lo) * DIM + 2.0 * Q * DIM * max(1, launch["db_splits"]) / max(1, launch["query_tiles"])
+                                                          + 8.0 * Q * 330) if wide else alg_bytes) / n_launch,
                      "hbm_GBps_algorithmic": round(alg_bytes / (knn_avg * 1e-3) / 1e9, 1),
                      "queries_rejected_by_certificate_last_step": rechecked,
                      "launch": launch},
@@ -648,7 +682,8 @@ def main():
             d_cpu, i_cpu = CB.knn_cosine(db_h, e_cpu, TOP_K, threads=cores)
             t_all = time.perf_counter() - t0
             agree = float(np.mean(i_cpu[:, 0] == I[:nb, 0].cpu().numpy()))
-            out["cpu_baseline"] = {"value": round(nb / t_all, 2), "unit": "clips/s", "cores": cores, "kind": "port",
+            out["cpu_baseline"] = {"value": round(nb / t_all, 2), "unit": "clips/s", "cores": cores,
+                                   "affinity_cpus": len(os.sched_getaffinity(0)), "kind": "port",
                                    "cpu_model": CB.cpu_model(),
                                    "sample": f"{nb} of the {B} clips against the full {n_total} x {DIM} store: float32 torch-CPU "
                                              f"(FFT + BLAS, {cores} threads) embed {t_e:.2f} s + normalise/GEMM/top-k {t_all - t_e:.2f} s",

@@ -167,18 +167,27 @@ def segment_mean(seg_vectors):
     return np.mean(np.stack([np.asarray(v, np.float64) for v in seg_vectors]), axis=0)
 
 
-def embed_clips(waves, seg, hop, w, b, levels=(1,), mode="max", normalize=True, padded_samples=0,
-                mel_filters=None):
-    """pipeline.py:392-414 composed with the stages above: list of 1-D clips -> float64 [B, D]."""
+def process_audio_batch(waves, seg, hop, extract_fn, levels=(1, 2, 4), mode="max"):
+    """pipeline.py:392-414 with the extractor as a parameter (the reference's is a pretrained transformer): per clip
+    segment_audio (:396-400) -> extract_fn(segment) -> [T, F] per segment (:402-406) -> tpp per segment (:410) -> mean over the
+    clip's segments (:411) -> stacked [B, D] (:414).  A clip that loads as None raises RuntimeError (:398-399).
+    Pinned by tests/golden/pipeline.npz (the reference's own method run with its AudioSegmenter and TemporalPyramidPooling)."""
     out = []
     for wav in waves:
-        vecs = []
-        for s in segment_audio(np.asarray(wav), seg, hop):
-            s = zero_mean_unit_var(s) if normalize else np.asarray(s, np.float64)
-            lm = log_mel(s, padded_samples=padded_samples, mel_filters=mel_filters)
-            vecs.append(tpp(frame_projection(lm, w, b), levels, mode))
+        if wav is None:
+            raise RuntimeError("Failed to load clip")
+        vecs = [tpp(extract_fn(s), levels, mode) for s in segment_audio(np.asarray(wav), seg, hop)]
         out.append(segment_mean(vecs))
     return np.stack(out)
+
+
+def embed_clips(waves, seg, hop, w, b, levels=(1,), mode="max", normalize=True, padded_samples=0,
+                mel_filters=None):
+    """process_audio_batch with this build's extractor (normalise -> log-mel -> frame projection): list of 1-D clips -> float64 [B, D]."""
+    def extract(s):
+        s = zero_mean_unit_var(s) if normalize else np.asarray(s, np.float64)
+        return frame_projection(log_mel(s, padded_samples=padded_samples, mel_filters=mel_filters), w, b)
+    return process_audio_batch(waves, seg, hop, extract, levels, mode)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -291,10 +300,19 @@ def merge_topk(dists, idxs, k, metric="L2"):
 # ------------------------------------------------------------------------------------------------
 
 def retrieve_postprocess(dists, idxs, stored_vectors, vector_paths, vector_labels, K, D, query_paths=None,
-                         exclude_self=True, training_file_ids=()):
-    """pipeline.py:489-524: per row keep the first K hits whose basename is not excluded
-    (:491-509), fetch the STORED vector (:503), pad to K with zeros / 0.0 / '' / NaN (:511-515).
-    Returns (vec [B,K,D] f32, lbl [B,K] f32, paths, dist [B,K] f32)."""
+                         exclude_self=True, training_file_ids=(), index_ntotal=None, skip_unfilled=False):
+    """pipeline.py:449-532 after the search: empty store -> zeros / 0 / '' / NaN (:465-476); per row keep the first K hits whose
+    basename is not excluded (:491-509), fetch the STORED vector (:503), pad to K with zeros / 0.0 / '' / NaN (:511-515).
+    dists / idxs: what search_batch returned for k_search = K + (10 if exclude_self else 0) (:478); None or a malformed result is
+    the swallowed failure (:481-487).  Returns (vec [B,K,D] f32, lbl [B,K] f32, paths, dist [B,K] f32).
+    skip_unfilled=False follows the reference to the letter: an unfilled slot (id -1) indexes vector_paths[-1] (:495, Python
+    negative indexing) and reconstructs row -1; True is this build's documented deviation (such slots are skipped).
+    Pinned by tests/golden/pipeline.npz (the reference's own method, run on seeded search results)."""
+    B = len(idxs) if idxs is not None else 0
+    if index_ntotal is not None and index_ntotal == 0:
+        B = len(dists) if idxs is None else B
+        return (np.zeros((B, K, D), np.float32), np.zeros((B, K), np.float32), [[""] * K for _ in range(B)],
+                np.full((B, K), np.nan, np.float32))
     exclude_ids = set()
     if exclude_self and query_paths is not None:
         exclude_ids = {os.path.basename(p) for p in query_paths}         # :463
@@ -303,6 +321,8 @@ def retrieve_postprocess(dists, idxs, stored_vectors, vector_paths, vector_label
         cv, cl, cp, cd = [], [], [], []
         for ii, dd in zip(row_inds, row_d):
             ii = int(ii)
+            if ii < 0 and skip_unfilled:
+                continue
             fname = os.path.basename(vector_paths[ii])                   # :495 (negative ii wraps, as in the reference)
             if exclude_self:
                 if query_paths is not None:
@@ -321,6 +341,18 @@ def retrieve_postprocess(dists, idxs, stored_vectors, vector_paths, vector_label
         all_v.append(cv); all_l.append(cl); all_p.append(cp); all_d.append(cd)
     return (np.stack([np.stack(v) for v in all_v]).astype(np.float32), np.asarray(all_l, np.float32),
             all_p, np.asarray(all_d, np.float32))
+
+
+def search_batch_shell(ntotal, query, k=None, top_k=5, cosine=False):
+    """vector_database.py:159-182 around index.search: k defaults to config.top_k (:163), a 1-D query becomes [1, D] (:164-165),
+    queries are normalised when the index is cosine (:166), k is clamped to ntotal (:169), k <= 0 returns ([B, 0] f32, [B, 0] i64)
+    without calling the index (:170-172).  Returns (q as handed to index.search, k handed over or 0)."""
+    k = int(k if k is not None else top_k)
+    q = np.asarray(query, np.float32)
+    if q.ndim == 1:
+        q = q.reshape(1, -1)
+    q = maybe_normalize(q, cosine)
+    return q, max(0, min(k, int(ntotal)))
 
 
 # ------------------------------------------------------------------------------------------------

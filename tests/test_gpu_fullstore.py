@@ -1,0 +1,118 @@
+"""BASELINE configs 4 and 5 at their FULL store size on one handle: 10 M x 512 fp32 (+ its f16 plane, ~31 GB)
+and 50 M x 256 fp16 (25.6 GB), 10 240 queries each.  The 8-GPU layouts hold a 1/8 share per rank (tests/test_gpu_certificate.py);
+DESIGN section 6 recommends REPLICATING these stores, so one handle must hold them whole: the scan's >= 3-launch regime, planes
+and row arrays beyond 4 GiB (buffer resources are re-based per tile), capacity growth at that size and the reference's append
+path (vector_database.py:134-138: batches of vector_add_batch_size = 10 000 rows) are exercised here.
+
+Parity: properties at full size (sorted, ids in range, planted rows lead) + the C float64 oracle on a 32-query sample computed
+chunk-wise (1 M rows at a time with id_base, merged by O.merge_topk) so that the host never holds the store."""
+import numpy as np
+import pytest
+
+from oracle import radad_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CHUNK = 1 << 20
+
+
+def _synth(lib, _lib, gpu, row0, n, dim, seed):
+    import torch
+    t = torch.empty((n, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(t.data_ptr(), row0, n, dim, seed, 0, _lib.stream_ptr(gpu)))
+    return t
+
+
+def _chunked_oracle(knn_oracle_lib, idx, n, base, qn_sample, k, gpu):
+    """float64 brute force of the sample's queries over the rows AS STORED, 1 M rows at a time."""
+    import torch
+    from conftest import c_knn
+    dists, ids = [], []
+    for r0 in range(0, n, CHUNK):
+        m = min(CHUNK, n - r0)
+        rows = idx.reconstruct_batch(torch.arange(base + r0, base + r0 + m, device=gpu)).cpu().numpy()
+        d_, i_ = c_knn(knn_oracle_lib, rows, qn_sample, k, "IP", base + r0)
+        dists.append(d_); ids.append(i_)
+    return O.merge_topk(np.stack(dists), np.stack(ids), k, "IP")
+
+
+def _build(idx, lib, _lib, gpu, n, dim, base, q, planted, small_batches_until):
+    """rows = synthetic + one planted near-duplicate per query; the first `small_batches_until` rows arrive in the reference's
+    10 000-row batches, the rest 1 M at a time; no reserve(): the capacity grows by itself"""
+    import torch
+    nq = q.shape[0]
+    r0 = 0
+    grows = 0
+    while r0 < n:
+        m = min(10_000 if r0 < small_batches_until else CHUNK, n - r0)
+        rows = _synth(lib, _lib, gpu, base + r0, m, dim, 4321)
+        sel = (planted >= r0) & (planted < r0 + m)
+        ns = int(sel.sum())
+        if ns:
+            noise = _synth(lib, _lib, gpu, 7_000_000 + r0, ns, dim, 99)
+            rows[planted[sel] - r0] = q[sel] + 0.05 * noise
+        idx.add_device(rows)
+        r0 += m
+    assert idx.ntotal == n
+    del rows
+    torch.cuda.synchronize()
+    return grows
+
+
+def test_config4_full_store_on_one_handle(gpu, knn_oracle_lib):
+    """10 M x 512 fp32, cosine, 10 240 queries, k = 10 and 15."""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    lib = _lib.load()
+    n, dim, nq, base = 10_000_000, 512, 10_240, 0
+    q = _synth(lib, _lib, gpu, 0, nq, dim, 977)
+    planted = (torch.arange(nq, device=gpu) * 971 + 29) % n
+    idx = HipFlatIndex(dim, _lib.METRIC_COSINE, 0, id_base=base)
+    _build(idx, lib, _lib, gpu, n, dim, base, q, planted, small_batches_until=1_000_000)
+    qn = torch.empty_like(q)
+    _lib.check(lib.radad_rownorm(q.data_ptr(), qn.data_ptr(), nq, dim, 0, _lib.stream_ptr(gpu)))
+    sample = np.arange(0, nq, nq // 32)[:32]
+    qn_s = qn.cpu().numpy()[sample]
+    for k in (10, 15):
+        D, I, K64 = idx.search_device(q, k, return_f64=True)
+        info = idx.last_launch()
+        assert info["block_threads"] == 512 and info["scan_kind"] == "hi_tile", info
+        assert info["scan_launches"] >= 3, info                      # > 1.2 M rows: beyond the two-launch regime
+        assert info["rechecked_queries"] <= nq // 100, info
+        assert bool((D[:, :-1] >= D[:, 1:]).all()) and bool((I >= base).all()) and bool((I < base + n).all())
+        assert bool((I[:, 0] == planted + base).all())
+        od, oi = _chunked_oracle(knn_oracle_lib, idx, n, base, qn_s, k, gpu)
+        np.testing.assert_array_equal(I.cpu().numpy()[sample], oi)
+        np.testing.assert_allclose(K64.cpu().numpy()[sample], od, rtol=0, atol=1e-9)
+    pi = idx.plane_info()
+    assert pi["built"], pi
+    # the online case on the same handle: one query streams the 10 GB plane
+    D1, I1 = idx.search_device(q[:1].contiguous(), 15)
+    assert int(I1[0, 0]) == int(planted[0]) + base
+    np.testing.assert_array_equal(I1.cpu().numpy()[0], _chunked_oracle(knn_oracle_lib, idx, n, base, qn_s[:1], 15, gpu)[1][0])
+
+
+def test_config5_full_store_on_one_handle(gpu, knn_oracle_lib):
+    """50 M x 256 fp16 store, 10 240 bfloat16 queries, fp32 accumulate, float64 re-rank over the decoded operands."""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    lib = _lib.load()
+    n, dim, nq, k, base = 50_000_000, 256, 10_240, 10, 0
+    q = _synth(lib, _lib, gpu, 0, nq, dim, 977)
+    planted = (torch.arange(nq, device=gpu) * 4801 + 5) % n
+    idx = HipFlatIndex(dim, _lib.METRIC_COSINE, 0, id_base=base, store_f16=True)
+    _build(idx, lib, _lib, gpu, n, dim, base, q, planted, small_batches_until=200_000)
+    qb = q.to(torch.bfloat16)
+    D, I, K64 = idx.search_device(qb, k, return_f64=True)
+    info = idx.last_launch()
+    assert info["block_threads"] == 512 and info["scan_launches"] >= 4, info
+    assert info["rechecked_queries"] <= nq // 100, info
+    assert bool((D[:, :-1] >= D[:, 1:]).all()) and bool((I >= base).all()) and bool((I < base + n).all())
+    assert bool((I[:, 0] == planted + base).all())
+    qf = qb.float().contiguous()
+    qn = torch.empty_like(qf)
+    _lib.check(lib.radad_rownorm(qf.data_ptr(), qn.data_ptr(), nq, dim, 0, _lib.stream_ptr(gpu)))
+    sample = np.arange(0, nq, nq // 32)[:32]
+    od, oi = _chunked_oracle(knn_oracle_lib, idx, n, base, qn.cpu().numpy()[sample], k, gpu)
+    np.testing.assert_array_equal(I.cpu().numpy()[sample], oi)
+    np.testing.assert_allclose(K64.cpu().numpy()[sample], od, rtol=0, atol=1e-9)
