@@ -89,6 +89,8 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
  *   RADAD_KNN_OPT_WIDE_MIN_Q smallest batch that takes the 256-query tile scan instead of the streaming kernels (default 17)
  *   RADAD_KNN_OPT_DENSE      1 (default) / 0: an fp32 store of <= 6144 rows (<= 16384 for <= 16 queries) is searched by writing out every
  *                            score and selecting on them / by the register-list kernels
+ *   RADAD_KNN_OPT_LIVE_FLOOR 1 (default) / 0: the certified tile scan covers the store in ONE launch and raises its admission floors inside
+ *                            it / in one launch per phase with a floor kernel between them (round 4's form)
  * The environment variables RADAD_KNN_HI, RADAD_KNN_CENTRE, RADAD_KNN_SMALLQ_HI, RADAD_WIDE_MIN_Q override the DEFAULTS of handles
  * created while they are set (announced once per process on stderr); the product path never needs them. */
 #define RADAD_KNN_OPT_HI_PLANE 0
@@ -96,6 +98,7 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
 #define RADAD_KNN_OPT_SMALLQ_HI 2
 #define RADAD_KNN_OPT_WIDE_MIN_Q 3
 #define RADAD_KNN_OPT_DENSE 4
+#define RADAD_KNN_OPT_LIVE_FLOOR 5
 int radad_knn_set_option(radad_knn_t h, int option, int value);
 int radad_knn_destroy(radad_knn_t h);
 int radad_knn_dim(radad_knn_t h, int* dim);
@@ -185,6 +188,9 @@ int radad_knn_last_scan_kind(radad_knn_t h, int* kind);
 /* scan-kernel launches of the last search (the certified tile scan covers a large store in two: the first eighth with the
  * sample's admission floor, the rest with the floor the first eighth's candidates give); radad_knn_profile_read has one entry each */
 int radad_knn_last_scan_launches(radad_knn_t h, int* n_launches);
+/* phases of the last search's tile scan: 1 + the number of times the admission floors were raised from the candidates emitted so far --
+ * inside the one launch (RADAD_KNN_OPT_LIVE_FLOOR, the default: 2 up to ~1.2 M rows, 3 up to ~9.5 M, 4 beyond) or between launches */
+int radad_knn_last_scan_phases(radad_knn_t h, int* n_phases);
 /* the f16 plane the certified scans read, once a search has built it: built (0/1); centred = the common component (column mean)
  * of the rows is subtracted before rounding (stores of embeddings that share most of their mean); one_scale = one power-of-two
  * scale for all rows (rows of one magnitude: the scan applies no per-score arithmetic) */
@@ -196,6 +202,13 @@ int radad_knn_plane_info(radad_knn_t h, int* built, int* centred, int* one_scale
  * (vector_database.py:134-138 appends 10 000 rows at a time; a store that drifts keeps the certified scan instead of the 8x slower
  * fp32 fallback).  Results never depend on it. */
 int radad_knn_plane_rebuilds(radad_knn_t h, int* n_out);
+/* The handle's self-tuning state, read WITHOUT synchronising (advisory; results never depend on it).  Every certified search leaves
+ * a report (queries rejected by the certificate, batch size) in pinned host memory when its device work ends; every later search
+ * acts on the reports that have arrived since -- however far the host has run ahead.  A batch of >= 64 queries rejected by more
+ * than a quarter first re-decides the plane (if rows were appended since), then widens the candidate buffers (cap_boost 1 -> 4),
+ * then moves to the fp32 kernels for 8 searches (fp32_searches_left).  reports_consumed counts the reports looked at so far.
+ * (The reference has no counterpart: faiss's flat search has one code path, vector_database.py:181.) */
+int radad_knn_tuning_info(radad_knn_t h, int* cap_boost, int* fp32_searches_left, int64_t* reports_consumed);
 /* Certificate of the most recent search (see radad_knn_search_f64): number of queries the float64 re-rank could NOT certify
  * and that were therefore searched again by the exact float64 kernel (results are exact either way).  Synchronises with
  * that search.  radad_knn_last_certificate additionally returns the batch size and stats6 = {rejected queries, sum over

@@ -9,12 +9,14 @@ from .config import Config
 from .segmenter import AudioSegmenter
 from .pooling import TemporalPyramidPooling
 from .vector_database import HipFlatIndex, HipIVFFlatIndex, VectorDatabase
-from .feature_extractor import MelProjectionFeatureExtractor, build_feature_extractor
+from .feature_extractor import (MelProjectionFeatureExtractor, Wav2Vec2FeatureExtractor, WavLMFeatureExtractor,
+                                WhisperFeatureExtractor, build_feature_extractor)
 from .pipeline import HotPathPipeline
 from .projection import ProjectionLayer
 from .radad_model import DetectionModel, RADADModel
 from .sharded import ReplicatedSearch, ShardedSearch, shard_bounds
 
 __all__ = ["Config", "AudioSegmenter", "TemporalPyramidPooling", "HipFlatIndex", "HipIVFFlatIndex", "VectorDatabase",
-           "MelProjectionFeatureExtractor", "build_feature_extractor", "HotPathPipeline", "ProjectionLayer", "DetectionModel", "RADADModel",
+           "MelProjectionFeatureExtractor", "Wav2Vec2FeatureExtractor", "WhisperFeatureExtractor", "WavLMFeatureExtractor",
+           "build_feature_extractor", "HotPathPipeline", "ProjectionLayer", "DetectionModel", "RADADModel",
            "ShardedSearch", "ReplicatedSearch", "shard_bounds"]

@@ -19,7 +19,7 @@ Q_F32, Q_BF16 = 0, 1
 OUT_F32, OUT_BF16 = 0, 1
 MAX_LEVELS = 8
 KNN_MAX_K = 1024
-KNN_OPT_HI_PLANE, KNN_OPT_CENTRE, KNN_OPT_SMALLQ_HI, KNN_OPT_WIDE_MIN_Q, KNN_OPT_DENSE = 0, 1, 2, 3, 4
+KNN_OPT_HI_PLANE, KNN_OPT_CENTRE, KNN_OPT_SMALLQ_HI, KNN_OPT_WIDE_MIN_Q, KNN_OPT_DENSE, KNN_OPT_LIVE_FLOOR = 0, 1, 2, 3, 4, 5
 IVF_OPT_HI_SCAN = 0
 IVF_SCAN_KINDS = ("f32_lists", "hi_lists", "exact_flat")
 EMBED_NO_SHARED_FRAMES, EMBED_LOGMEL_F32, EMBED_LOGMEL_DFT_GEMM = 1, 2, 4
@@ -75,8 +75,10 @@ SIGNATURES = {
     "radad_knn_search_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "radad_knn_search_abort": (C.c_int, [C.c_void_p]),
     "radad_knn_last_scan_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "radad_knn_last_scan_phases": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_plane_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "radad_knn_plane_rebuilds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "radad_knn_tuning_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "radad_kth_largest": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "radad_knn_last_scan_kind": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_search_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),

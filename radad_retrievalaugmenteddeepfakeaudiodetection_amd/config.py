@@ -44,6 +44,12 @@ class Config:
         self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         # extractor selection (config.py:92).  "melproj" is this build's native extractor.
         self.feature_extractor_type = "melproj"
+        # the reference's three encoders (config.py:42-45).  The reference fetches these NAMES from the hub; here each must be a local
+        # directory in save_pretrained layout (nothing is downloaded): feature_extractor.py's adapters run the front-end in HIP
+        self.wav2vec2_model_name = "facebook/wav2vec2-base-960h"
+        self.whisper_model_name = "openai/whisper-base"
+        self.wavlm_model_name = "microsoft/wavlm-base"
+        self.wav2vec2_layers_to_use = [-4, -3, -2, -1]
         # ---- knobs added by this build -------------------------------------------------------------
         self.feature_dim = 512              # F of the frame projection (injected by main.py:66 in the reference)
         self.melproj_normalize = True       # per-segment zero-mean/unit-variance before the spectrogram
@@ -60,6 +66,7 @@ class Config:
         self.knn_smallq_hi = None           # False: batches of <= 16 queries stream the fp32 rows
         self.knn_wide_min_q = None          # smallest batch on the 256-query tile scan (default 17)
         self.knn_dense = None               # 0: fp32 stores of a few thousand rows stay on the register-list kernels
+        self.knn_live_floor = None          # 0: the tile scan runs one launch per phase (round 4) instead of one launch that raises its floors
 
     def update(self, **kwargs):
         """config.py:109-115."""

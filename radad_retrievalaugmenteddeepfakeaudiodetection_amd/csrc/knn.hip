@@ -1278,8 +1278,11 @@ __global__ __launch_bounds__(RF_THREADS) void k_kth_floor(KthParams p) {
 // index = no entry), lowered by 2 eps -- a_k over the WHOLE store is >= the rank-th best of any subset for rank >= k, so the
 // floor is <= tau = a_k - 2 eps always.  -inf when the sample holds fewer entries.  One workgroup per query (k_thr_from_parts, its
 // predecessor, walked the 512 list heads `rank` times with a wave: 19 us against 6).
+// clear / clear_n (optional): the query's candidate-score buffer, set to -inf -- the scan that raises its floors inside the launch reads
+// other workgroups' candidates while they are being written: a slot reserved but not written yet must read as "no entry".
 __global__ __launch_bounds__(RF_THREADS) void k_floor_from_sample(const float* __restrict__ score, const int* __restrict__ idx, int n_ent, int rank,
-                                                                 const float* __restrict__ eps, float* __restrict__ thr) {
+                                                                 const float* __restrict__ eps, float* __restrict__ thr,
+                                                                 float* __restrict__ clear, int clear_n) {
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     float* e_sc = reinterpret_cast<float*>(smem_f);                      // [n_ent]
     int* hist = reinterpret_cast<int*>(e_sc + n_ent);                    // [256]
@@ -1287,6 +1290,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_floor_from_sample(const float* _
     const int64_t q = blockIdx.x;
     for (int i = threadIdx.x; i < n_ent; i += RF_THREADS)
         e_sc[i] = idx[q * n_ent + i] != IDX_SENTINEL ? score[q * n_ent + i] : -INFINITY;
+    if (clear) for (int i = threadIdx.x; i < clear_n; i += RF_THREADS) clear[q * clear_n + i] = -INFINITY;
     const float a = radix_select_kth(e_sc, n_ent, rank, hist, xchg);
     if (threadIdx.x == 0) thr[q] = a > -INFINITY ? a - 2.f * eps[q] : -INFINITY;
 }
@@ -1888,8 +1892,9 @@ struct ExactParams {
     int* pidx;
     int64_t id_base;
     float* out_dist; int64_t* out_idx; double* out_key;
-    int* host_stats;           // pinned host memory (device-visible): the kernel leaves the search's 6 counters there, then ...
+    int* host_stats;           // pinned host memory (device-visible): the kernel leaves the search's 6 counters and its batch size ([7]) there, then ...
     int stamp;                 // ... this value in host_stats[6] (the search's sequence number + 1): the host reads a report only when its stamp is there
+    int nq_report;             // the search's batch size (travels with the report: the host may be many searches ahead when it reads it)
     int* arrive;               // [query groups] arrival counters of the slices (zero between launches: the last arrival resets its own)
 };
 
@@ -1899,7 +1904,10 @@ __device__ __forceinline__ void exact_merge_slot(const ExactParams& p, int slot,
 __global__ __launch_bounds__(KX_THREADS) void k_exact_scan(ExactParams p) {
     const int count = *p.count;
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && p.host_stats) {
+        *reinterpret_cast<volatile int*>(&p.host_stats[6]) = 0;          // the slot is being rewritten: no report until the new stamp is there
+        __threadfence_system();
         for (int i = 0; i < 6; ++i) p.host_stats[i] = p.count[i];       // count + 5 statistics
+        p.host_stats[7] = p.nq_report;
         __threadfence_system();
         *reinterpret_cast<volatile int*>(&p.host_stats[6]) = p.stamp;
     }
@@ -2283,6 +2291,7 @@ struct SearchCtx {
                                        // kernels' L2 score 2 q.y - |y|^2 lacks the -|q|^2: a cross-shard bound does not apply to it
     const float* q_use = nullptr;       // fp32 queries as the re-rank reads them (caller's buffer, or the workspace's normalised copy)
     bool have_ak = false;              // k_kth_floor left a_k in the workspace (o_ak)
+    bool hi_tile = false;              // the certified f16 tile scan took this search
     size_t o_ak = 0;
     size_t o_eps = 0, o_thr = 0, o_cnt = 0, o_fcount = 0, o_fsel = 0, o_ps = 0, o_pi = 0, o_xk = 0, o_xi = 0;
 };
@@ -2305,6 +2314,8 @@ struct radad_knn_s {
     int opt_smallq_hi = 1;       // small batches stream the f16 plane (0: the fp32 rows)
     int opt_wide_min_q = 17;     // smallest batch that takes the 256-query tile scan
     int opt_dense = 1;           // stores of <= RF_STAGE_MAX rows: all scores + select (k_knn_dense) instead of the register-list kernels
+    int opt_live_floor = 1;      // the tile scan covers the store in ONE launch and raises its admission floors inside it (0: one launch per phase)
+    int last_scan_phases = 0;    // (radad_knn_last_scan_phases)
     unsigned* stat = nullptr;    // device [3] float bits: max |y'|, max |y' - yh| (y' = y - mu when the plane is centred, else y) and
                                  // max |y| over rows [0, stat_rows)
     int64_t stat_rows = 0;
@@ -2322,11 +2333,25 @@ struct radad_knn_s {
     int uniform_e = HI_E_PER_ROW; // one power-of-two scale 2^e for every row of the plane (rows of one magnitude), or HI_E_PER_ROW
     // queries the certificate rejected in the most recent search: counted on the device, copied to pinned host memory
     // behind the search (no synchronisation inside search); feeds the adaptive choice below and radad_knn_last_recheck
-    // The counters of search i land in slot i % 2 and are CONSUMED by search i + 2 behind a wait on that slot's event (long due by
-    // then: the host is never more than two searches ahead of the device), so which kernels a search sequence runs does not depend
-    // on host / device timing -- the first version polled the previous search's event with hipEventQuery and could take the f16
-    // scan in one run and the fp32 scan in another.
-    int* host_count = nullptr;   // pinned [2][8]: rejected queries, sum of candidates, rejections by reason x 4, [6] the report's stamp
+    // The counters of search i land in slot i % 2 of pinned host memory, written by k_exact_scan together with the search's batch size
+    // and, last, its stamp (sequence number + 1).  Every later search looks at BOTH slots without waiting and acts on any report it
+    // has not consumed yet (stamp_seen) that belongs to a search issued since the last tuning change (tuned_at) -- however far the
+    // host runs ahead of the device (round 4 acted only on the report of exactly search_seq - 2: a host more than two searches
+    // ahead, e.g. a queued bench loop, never saw one).  WHEN a report is first seen depends on host / device timing, so
+    // the search at which a handle retunes may differ between runs; what a search returns never does (exact by construction).
+    int* host_count = nullptr;   // pinned [2][8]: rejected queries, sum of candidates, rejections by reason x 4, [6] the report's stamp, [7] its batch size
+    int stamp_seen[2] = {0, 0};  // stamp of the last report consumed from each slot
+    // LOOKING before the exact pass.  The exact float64 kernel costs nq x ntotal x dim multiply-adds for a fully rejected batch: 10 s for
+    // 10 240 queries against 10 M x 512 (BASELINE config 4 with a store whose planted rows neighbour EVERY query: 73 % of the batch
+    // overflowed its 1024 candidates), and a host that queues searches gets no report before it has queued them all.  So the first
+    // large tile-scan search after anything that can change the outcome (handle creation, a plane (re)build, a tuning step, the end of
+    // an fp32 fallback) WAITS for its re-rank -- one stream synchronisation -- and, when more than a quarter of the batch was rejected,
+    // retunes and runs again at once instead of entering the exact kernel.  A search that passes clears the flag: steady state never
+    // synchronises.
+    bool verify_next = true;
+    int hi_fail_streak = 0;      // consecutive returns from the fp32 fallback that were rejected again: the fallback doubles (8, 16, ... 512 searches)
+    int64_t verified_retries = 0;
+    int64_t reports_consumed = 0;   // (radad_knn_tuning_info)
     bool owned_serial = false;   // the handle is private to another object that orders its calls itself (the IVF index's centroid store): no ev_done
     int* host_count_dev = nullptr;   // the same memory as the device sees it
     hipEvent_t ev_done = nullptr;
@@ -2532,6 +2557,7 @@ static bool knn_ensure_hi(radad_knn_t h, hipStream_t st, bool want_plane) {
     if (fresh) {
         (void)hipDeviceSynchronize();
         knn_drop_plane(h);
+        h->verify_next = true;                           // a new plane: the next large search looks at its certificate before the exact pass
         const bool centred = knn_choose_centre(h, st);
         // One scale for the whole plane when the rows are of one magnitude (the largest row maximum within 2^6 of the smallest over
         // the rows the store holds now: clip embeddings are; rows scaled over 2^22, as a test does, are not): the scan then needs
@@ -2650,14 +2676,14 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
     { const char* e = radad_env_override("RADAD_WIDE_MIN_Q", "smallest batch that takes the 256-query tile scan (default 17)"); h->opt_wide_min_q = e ? atoi(e) : SQ_NQ + 1; }
     {
         DeviceGuard g(device);
-        if (hipHostMalloc(reinterpret_cast<void**>(&h->host_count), 16 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc(reinterpret_cast<void**>(&h->host_count), 24 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&h->ev_begun, hipEventDisableTiming) != hipSuccess) {
             radad_set_error("radad_knn_create: pinned counter / events could not be created");
             radad_knn_destroy(h);
             return RADAD_EHIP;
         }
-        memset(h->host_count, 0, 16 * sizeof(int));
+        memset(h->host_count, 0, 24 * sizeof(int));
         if (hipHostGetDevicePointer(reinterpret_cast<void**>(&h->host_count_dev), h->host_count, 0) != hipSuccess) {
             radad_set_error("radad_knn_create: pinned counter is not device-visible");
             radad_knn_destroy(h);
@@ -2723,6 +2749,10 @@ int radad_knn_set_option(radad_knn_t h, int option, int value) {
         case RADAD_KNN_OPT_DENSE:
             RADAD_REQUIRE(value == 0 || value == 1, "radad_knn_set_option: DENSE takes 0 or 1");
             h->opt_dense = value;
+            return RADAD_OK;
+        case RADAD_KNN_OPT_LIVE_FLOOR:
+            RADAD_REQUIRE(value == 0 || value == 1, "radad_knn_set_option: LIVE_FLOOR takes 0 or 1");
+            h->opt_live_floor = value;
             return RADAD_OK;
         default:
             radad_set_error("radad_knn_set_option: unknown option %d", option);
@@ -2884,6 +2914,16 @@ static int knn_tile_ksplit(radad_knn_t h, int qtiles_grid, int n_splits, int64_t
 // and scans, and can report per query a lower bound of the exact k-th best score of THIS store; phase 2 re-ranks -- with the
 // maximum of the shards' bounds, only what can still be among the global k best -- and runs the exact kernel.
 
+// a batch was mostly rejected by the certificate: re-decide the plane if rows were appended since it was decided, else widen the
+// candidate buffers, else leave the f16 kernels for a while (8 searches, doubling while every return is rejected again)
+static void knn_retune_after_mass_rejection(radad_knn_t h) {
+    if (h->hi && h->ntotal > h->plane_decided_rows) h->replan = true;
+    else if (h->cap_boost == 1) h->cap_boost = 4;
+    else { h->hi_skip = 8 << std::min(h->hi_fail_streak, 6); ++h->hi_fail_streak; }
+    h->tuned_at = h->search_seq;
+    h->verify_next = true;
+}
+
 // the most recent search's device work is complete (its statistics are in the pinned host copy)
 static hipError_t knn_wait_last_search(radad_knn_t h) {
     if (!h->have_last) return hipSuccess;
@@ -2903,23 +2943,35 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         if (hipEventRecord(h->ev_done, h->last_stream) == hipSuccess) RADAD_HIP_CHECK(hipStreamWaitEvent(st, h->ev_done, 0));
         else { (void)hipGetLastError(); RADAD_HIP_CHECK(hipDeviceSynchronize()); }      // (that stream no longer exists)
     }
+    // from here on this search's kernels go to `st` and use the handle's workspace: whatever comes next -- also after an error return
+    // or radad_knn_search_abort between the halves -- orders itself behind `st` (until round 4 this was only recorded at the END
+    // of phase 2: a search on another stream after an aborted one shared the workspace with kernels still running)
+    h->last_stream = st;
+    h->have_last = true;
 
     h->prof.next_search();
     const bool cert = k <= KNN_CERT_MAX_K;      // beyond: legacy k + margin candidates, no certificate
-    // how the certificate of the search TWO back fared (fixed lag: see the handle); this search takes over its slot
-    const int cslot = (int)(h->search_seq & 1);
+    // how the certificates of earlier searches fared: any report that has arrived and was not looked at yet (see the handle); this
+    // search takes over slot search_seq & 1
     // (until round 4 an event behind every search was waited for here: an event record between dependent kernels costs the stream ~6 us,
-    // a tenth of an online search.  The exact kernel now stamps its report; one that has not arrived yet is simply not looked at.)
-    if (cert && h->search_seq >= 2 && *reinterpret_cast<volatile int*>(&h->host_count[8 * cslot + 6]) == (int)((h->search_seq - 2) & 0x3fffffff) + 1) {
+    // a tenth of an online search.  The exact kernel stamps its report; one that has not arrived yet is simply not looked at.)
+    for (int sl = 0; cert && sl < 2; ++sl) {
+        volatile int* rep = reinterpret_cast<volatile int*>(h->host_count + 8 * sl);
+        const int stamp = rep[6];
+        if (stamp == 0 || stamp == h->stamp_seen[sl]) continue;
         std::atomic_thread_fence(std::memory_order_acquire);
-        // (the report is that of search search_seq - 2: if the plane or the buffers were changed since, it says nothing about them)
-        if (h->hi_skip == 0 && h->count_nq[cslot] >= 64 && (int64_t)h->host_count[8 * cslot] * 4 > h->count_nq[cslot] &&
-            h->search_seq >= h->tuned_at + 2) {
-            if (h->hi && h->ntotal > h->plane_decided_rows) { h->replan = true; h->tuned_at = h->search_seq; }      // the store has changed since the plane was decided: decide again
-            else if (h->cap_boost == 1) { h->cap_boost = 4; h->tuned_at = h->search_seq; }                         // first: four times the candidate buffer
-            else h->hi_skip = 8;                                                  // the same plane would come back: fp32 kernels for a while
-        }
+        const int rejected = rep[0], rep_nq = rep[7];
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (rep[6] != stamp) continue;                    // the device is rewriting the slot right now: next search
+        h->stamp_seen[sl] = stamp;
+        ++h->reports_consumed;
+        // the report's own search: the one search at or below search_seq with that stamp's low 30 bits
+        const uint64_t cur30 = h->search_seq & 0x3fffffff, rep30 = (uint64_t)(stamp - 1);
+        const uint64_t rep_seq = h->search_seq - ((cur30 - rep30) & 0x3fffffff);
+        // (a report from before the last change of the plane or of the buffers says nothing about them)
+        if (h->hi_skip == 0 && rep_nq >= 64 && (int64_t)rejected * 4 > rep_nq && rep_seq >= h->tuned_at) knn_retune_after_mass_rejection(h);
     }
+    const int cslot = (int)(h->search_seq & 1);
 #ifdef RADAD_DEBUG_HOOKS
     if (getenv("RADAD_DEBUG_KNN")) h->hi_skip = 0;     // timing ablations (wrong results, every query rejected): stay on the kernel under test
 #endif
@@ -2959,7 +3011,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             s_splits = (int)std::min<int64_t>(std::min<int64_t>(KW_SAMPLE_SPLITS, want), tiles / 8 / 8 * 8);
         }
         if (s_splits >= 8 && s_splits * KW_SAMPLE_LIST >= 2 * ksel) {
-            if (h->hi_skip > 0) { --h->hi_skip; skipped_hi = true; }
+            if (h->hi_skip > 0) { --h->hi_skip; skipped_hi = true; if (h->hi_skip == 0) h->verify_next = true; }
             else if (knn_ensure_hi(h, st, true)) { use_hi = true; n_qtiles = wq; }
         }
     }
@@ -3038,7 +3090,10 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     const size_t b_qn = h->metric == RADAD_METRIC_COSINE ? qrow_f32 : 0;
     const size_t b_qh = (use_hi || f16_tile || smallq_hi) ? al256((size_t)nq * h->dim * 2) : 0;
     const size_t b_vec = al256((size_t)nq * sizeof(float));
-    const size_t part_elems = (size_t)nq * std::max<size_t>((size_t)n_parts * plen, use_hi ? (size_t)KW_SAMPLE_SPLITS * KW_SAMPLE_LIST : 0);
+    // (the sample pre-pass's lists live BEHIND the candidate buffers, not in them: k_floor_from_sample clears a query's buffer to -inf
+    // while other queries' sample lists are still being read)
+    const size_t cand_elems = (size_t)nq * (size_t)n_parts * plen;
+    const size_t part_elems = cand_elems + (use_hi ? (size_t)nq * KW_SAMPLE_SPLITS * KW_SAMPLE_LIST : 0);
     const size_t b_part = al256(part_elems * sizeof(float));
     const size_t b_xk = cert ? al256((size_t)nq * KX_SLICES * k * sizeof(double)) : 0;
     const size_t b_xi = cert ? al256((size_t)nq * KX_SLICES * k * sizeof(int)) : 0;
@@ -3132,6 +3187,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         wp.cand_cap = emit_cap; wp.cand_cnt = cand_cnt;
         wp.thr_init = nullptr;
         wp.ksplit = 1; wp.kacc = nullptr; wp.kflag = nullptr; wp.loose_floor = 0; wp.chunk_stride = 0;
+        wp.floor_live = nullptr; wp.eps = nullptr; wp.k_sel = 0; wp.refresh_at[0] = wp.refresh_at[1] = wp.refresh_at[2] = wp.refresh_at[3] = 0;
         wp.debug = 0; wp.stamps = nullptr;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (make exp); never in the shipped library
         { const char* dbg = getenv("RADAD_DEBUG_KNN"); wp.debug = dbg ? atoi(dbg) : 0; }
@@ -3152,9 +3208,26 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
                                reinterpret_cast<const void*>(k_knn_hi_sample<2>), reinterpret_cast<const void*>(k_knn_hi_sample<3>)};
         RADAD_HIP_CHECK(hipFuncSetAttribute(fns[rsc], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         RADAD_HIP_CHECK(hipFuncSetAttribute(sfns[rsc], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        // ONE launch over the whole store with the floors raised inside it (knn_hi.inc: floor_live), when the candidate buffers are the
+        // 1024 entries a wave holds in registers and a workgroup's chunk is long enough to refresh at least once before the sample's
+        // floor alone would fill them: after t tiles of every resident chunk stream ~t x 256 x (streams per query tile) rows have been
+        // scanned, and the phases of the launch-per-phase form (8 x the sample, 8 x that, ...) become refresh points t, 8 t, 64 t.
+        // Round 4 ran one launch per phase (2 up to 1.2 M rows, 3 up to 9.5 M, k_kth_floor between them): every launch has its ramp
+        // and its tail, and a 100 k-row store (BASELINE config 2) ran 64 + 327 tiles as 1 + 3 tile times on 512 workgroups.
+        int live_nr = 0, live_at[4] = {0, 0, 0, 0};
+        const bool one_go = (int64_t)ksel * h->ntotal <= (int64_t)(emit_cap / 3) * s_splits * KW_M;
+        if (!one_go && emit_cap <= 1024 && h->opt_live_floor) {
+            int gq, gs; int64_t gc;
+            knn_geometry_wide(h->ntotal, nq, &gq, &gs, &gc);
+            const int gq_grid = gq <= 8 ? gq : (gq + 7) / 8 * 8;
+            const int64_t streams = std::max<int64_t>(1, std::min<int64_t>(gs, 256 / std::max(1, std::min(gq_grid, 256))));
+            const int64_t c_tiles = gc / KW_M;
+            for (int64_t t = std::max<int64_t>(1, ceil_div64(hi_phase0, (int64_t)KW_M * streams)); t < c_tiles && live_nr < 4; t *= 8)
+                live_at[live_nr++] = (int)t;
+        }
         // sample pre-pass: the (k + margin)-th best score over the first rows of the store is a score at least k rows reach, so the
         // scan admits from it (minus 2 eps) instead of -inf (the score of a (row, query) pair does not depend on the tiling).
-        // It uses the head of the candidate arrays; the scan overwrites them afterwards.
+        // Its lists live behind the candidate buffers.
         {
             KnnHiParams sp = wp;
             // The sample's tiles are SPREAD over the store (every (tiles / s_splits)-th one).  The first s_splits tiles, as until round 4,
@@ -3163,6 +3236,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             // from rows of the first -- so loose that every row of its own cluster passed it, the candidate buffer overflowed and the
             // certificate rejected all 256 queries of a batch (tests/test_gpu_reference_shapes.py::test_a_store_that_drifts...).
             sp.n = h->ntotal; sp.n_splits = s_splits; sp.chunk_rows = KW_M;
+            sp.part_score = ps + cand_elems; sp.part_idx = pi + cand_elems;
             sp.chunk_stride = std::max<int64_t>(1, (h->ntotal / KW_M) / s_splits) * KW_M;
             const int sq_grid = sp.n_qtiles <= 8 ? sp.n_qtiles : (sp.n_qtiles + 7) / 8 * 8;
             // (the K split's scratch is indexed by row0 / KW_M: the sample's tiles lie anywhere in the store)
@@ -3174,8 +3248,8 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             else if (rsc == 2) hipLaunchKernelGGL(k_knn_hi_sample<2>, sg, sb, lds, st, sp);
             else hipLaunchKernelGGL(k_knn_hi_sample<3>, sg, sb, lds, st, sp);
             const int n_ent = sp.n_splits * KW_SAMPLE_LIST;
-            hipLaunchKernelGGL(k_floor_from_sample, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)n_ent * 4 + 1040, st, (const float*)ps,
-                               (const int*)pi, n_ent, k + margin, (const float*)eps, thr_init);
+            hipLaunchKernelGGL(k_floor_from_sample, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)n_ent * 4 + 1040, st, (const float*)sp.part_score,
+                               (const int*)sp.part_idx, n_ent, k + margin, (const float*)eps, thr_init, live_nr > 0 ? ps : (float*)nullptr, emit_cap);
             wp.thr_init = thr_init;
         }
         const dim3 b(KW_THREADS);
@@ -3186,7 +3260,11 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             rp.rscale = wp.rscale ? wp.rscale + r0 : nullptr;
             rp.rbias = wp.rbias ? wp.rbias + r0 : nullptr;
             rp.n = r1 - r0; rp.id_off = r0;
-            rp.loose_floor = (r0 == 0 && r1 == h->ntotal && s_splits < KW_SAMPLE_SPLITS) ? 1 : 0;      // one launch behind a small sample
+            rp.loose_floor = (r0 == 0 && r1 == h->ntotal && s_splits < KW_SAMPLE_SPLITS && live_nr == 0) ? 1 : 0;      // one launch behind a small sample
+            if (live_nr > 0) {
+                rp.floor_live = thr_init; rp.eps = eps; rp.k_sel = k;
+                for (int i = 0; i < 4; ++i) rp.refresh_at[i] = live_at[i];
+            }
             int gq, gs; int64_t gc;
             knn_geometry_wide(rp.n, nq, &gq, &gs, &gc);
             rp.n_splits = gs; rp.chunk_rows = gc; rp.chunk_stride = gc;
@@ -3204,7 +3282,13 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             h->prof.end(st);
         };
         h->last_scan_launches = 0;
-        for (int64_t r0 = 0, span = hi_phase0; r0 < h->ntotal; span *= 8) {
+        h->last_scan_phases = 0;
+        if (live_nr > 0) {
+            launch_range(0, h->ntotal);
+            h->last_scan_launches = 1;
+            h->last_scan_phases = 1 + live_nr;
+        }
+        for (int64_t r0 = 0, span = hi_phase0; live_nr == 0 && r0 < h->ntotal; span *= 8) {
             // (a last phase of less than a quarter of its predecessor is not worth a launch of its own: it joins it)
             int64_t r1 = std::min<int64_t>(h->ntotal, r0 + span);
             if (h->ntotal - r1 < span / 4) r1 = h->ntotal;
@@ -3236,6 +3320,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             }
             launch_range(r0, r1);
             ++h->last_scan_launches;
+            ++h->last_scan_phases;
             r0 = r1;
         }
 #ifdef RADAD_DEBUG_HOOKS
@@ -3348,7 +3433,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
 
     ctx->valid = true;
     ctx->nq = nq; ctx->k = k; ctx->l2 = l2; ctx->cslot = cslot; ctx->n_parts = n_parts; ctx->plen = plen; ctx->cap = cap; ctx->xgroup = xgroup;
-    ctx->cert = cert; ctx->emit = use_hi || dense; ctx->use_floor = use_hi; ctx->q_use = q_use;
+    ctx->cert = cert; ctx->emit = use_hi || dense; ctx->use_floor = use_hi; ctx->hi_tile = use_hi; ctx->q_use = q_use;
     ctx->small_lists = !use_hi && !dense && (smallq || smallq_hi);
     ctx->canonical = use_hi || smallq_hi || !l2;
     ctx->have_ak = lb_out != nullptr && use_hi && cert; ctx->o_ak = o_ak;
@@ -3357,7 +3442,8 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     return RADAD_OK;
 }
 
-static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* global_lb, float* out_dist_dev, int64_t* out_idx_dev,
+constexpr int RADAD_RETRY_INTERNAL = 1;      // knn_search_phase2 -> knn_search_core: retuned after a mass rejection, run the search again
+static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* global_lb, bool may_retry, float* out_dist_dev, int64_t* out_idx_dev,
                              double* out_key_dev, hipStream_t st) {
     char* ws = (char*)h->ws;
     int* flag_count = (int*)(ws + c.o_fcount);
@@ -3412,6 +3498,19 @@ static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* glo
     }
     RADAD_HIP_CHECK(hipGetLastError());
 
+    // ---- look before the exact pass (see radad_knn_s::verify_next) ---------------------------------------------------------------
+    if (c.cert && c.hi_tile && h->verify_next && nq >= 64 && (double)nq * (double)h->ntotal * (double)h->dim >= 4e11) {
+        int* rej = h->host_count + 16;
+        RADAD_HIP_CHECK(hipMemcpyAsync(rej, flag_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        RADAD_HIP_CHECK(hipStreamSynchronize(st));
+        if ((int64_t)*rej * 4 > nq && may_retry) {
+            knn_retune_after_mass_rejection(h);
+            ++h->verified_retries;
+            return RADAD_RETRY_INTERNAL;
+        }
+        if ((int64_t)*rej * 4 <= nq) { h->verify_next = false; h->hi_fail_streak = 0; }
+    }
+
     // ---- the queries the certificate rejected: exact float64 search, sized and driven by the device-side count ------
     if (c.cert) {
         ExactParams x;
@@ -3420,7 +3519,7 @@ static int knn_search_phase2(radad_knn_t h, const SearchCtx& c, const float* glo
         x.slice_rows = ceil_div64(std::max<int64_t>(h->ntotal, 1), KX_SLICES);
         x.pkey = (double*)(ws + c.o_xk); x.pidx = (int*)(ws + c.o_xi); x.id_base = h->id_base;
         x.out_dist = out_dist_dev; x.out_idx = out_idx_dev; x.out_key = out_key_dev;
-        x.host_stats = h->host_count_dev + 8 * c.cslot; x.stamp = (int)(h->search_seq & 0x3fffffff) + 1;
+        x.host_stats = h->host_count_dev + 8 * c.cslot; x.stamp = (int)(h->search_seq & 0x3fffffff) + 1; x.nq_report = (int)std::min<int64_t>(nq, 0x7fffffff);
         const size_t xlds = (size_t)c.xgroup * h->dim * 4 + (size_t)KX_WAVES * c.xgroup * k * 12 + 16;
         RADAD_REQUIRE(xlds <= 160 * 1024, "radad_knn_search: dim %d x k %d too large for the exact kernel", h->dim, k);
         RADAD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_exact_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)xlds));
@@ -3459,10 +3558,13 @@ static int knn_search_core(radad_knn_t h, const void* q_in, int q_dtype, int64_t
     std::lock_guard<std::mutex> lk(h->mu);
     DeviceGuard g(h->device);
     RADAD_REQUIRE(!h->pending.valid, "radad_knn_search: a radad_knn_search_begin on this handle has not been finished");
-    SearchCtx c;
-    int rc = knn_search_phase1(h, q_in, q_dtype, nq, k, margin, nullptr, (hipStream_t)stream, &c);
-    if (rc) return rc;
-    return knn_search_phase2(h, c, nullptr, out_dist_dev, out_idx_dev, out_key_dev, (hipStream_t)stream);
+    for (int attempt = 0;; ++attempt) {       // (at most: plane re-decided, buffers widened, fp32 kernels)
+        SearchCtx c;
+        int rc = knn_search_phase1(h, q_in, q_dtype, nq, k, margin, nullptr, (hipStream_t)stream, &c);
+        if (rc) return rc;
+        rc = knn_search_phase2(h, c, nullptr, attempt < 3, out_dist_dev, out_idx_dev, out_key_dev, (hipStream_t)stream);
+        if (rc != RADAD_RETRY_INTERNAL) return rc;
+    }
 }
 
 extern "C" {
@@ -3501,7 +3603,7 @@ int radad_knn_search_finish(radad_knn_t h, const float* global_lower_bound_dev, 
     const SearchCtx c = h->pending;
     h->pending.valid = false;
     RADAD_HIP_CHECK(hipStreamWaitEvent((hipStream_t)stream, h->ev_begun, 0));       // the scan of _begin (no-op on the same stream)
-    return knn_search_phase2(h, c, global_lower_bound_dev, out_dist_dev, out_idx_dev, out_key_dev, (hipStream_t)stream);
+    return knn_search_phase2(h, c, global_lower_bound_dev, false, out_dist_dev, out_idx_dev, out_key_dev, (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -3634,6 +3736,22 @@ int radad_knn_plane_rebuilds(radad_knn_t h, int* n_out) {
     RADAD_REQUIRE(h && n_out, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
     *n_out = h->plane_rebuilds;
+    return RADAD_OK;
+}
+
+int radad_knn_last_scan_phases(radad_knn_t h, int* n_phases) {
+    RADAD_REQUIRE(h && n_phases, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    *n_phases = h->last_scan_phases;
+    return RADAD_OK;
+}
+
+int radad_knn_tuning_info(radad_knn_t h, int* cap_boost, int* fp32_searches_left, int64_t* reports_consumed) {
+    RADAD_REQUIRE(h && cap_boost && fp32_searches_left && reports_consumed, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    *cap_boost = h->cap_boost;
+    *fp32_searches_left = h->hi_skip;
+    *reports_consumed = h->reports_consumed;
     return RADAD_OK;
 }
 

@@ -241,15 +241,160 @@ class MelProjectionFeatureExtractor:
         return self._stage(self._lib.radad_embed_logmel, audio_segments, (self.num_frames, N_MELS))
 
 
+# ---- the reference's three named extractors: HIP front-end + a locally stored HuggingFace encoder ---------------------------------
+# The reference fetches processor and model by NAME from the hub (feature_extractor.py:14-15, :70-71, :131-132).  Here the configured
+# name is a LOCAL directory (save_pretrained layout; `local_files_only=True`: nothing is ever fetched): the front-end the HF processor
+# would run on the CPU -- zero-mean / unit-variance (K1) or the 30 s-padded Whisper log-mel (K2) -- runs in csrc/embed.hip, the encoder
+# forward is the HuggingFace module itself on the ROCm device (third-party arithmetic with third-party weights: not reproduced).
+
+def _local_model_dir(name, what):
+    import os
+    if not isinstance(name, str) or not os.path.isdir(name) or not os.path.isfile(os.path.join(name, "config.json")):
+        raise FileNotFoundError(
+            f"{what}: {name!r} is not a local model directory (expected config.json + weights as written by save_pretrained).  This "
+            "build never downloads: point the config's model name at a local copy of the encoder the reference fetches from the hub "
+            "(feature_extractor.py:14-15,70-71,131-132), or use feature_extractor_type='melproj'.")
+    return name
+
+
+def _preprocessor_flag(model_dir, key, default):
+    """one key of the directory's preprocessor_config.json (what the HF processor's from_pretrained would read)"""
+    import json
+    import os
+    path = os.path.join(model_dir, "preprocessor_config.json")
+    if os.path.isfile(path):
+        with open(path) as f:
+            return json.load(f).get(key, default)
+    return default
+
+
+class _FrontEnd(MelProjectionFeatureExtractor):
+    """the HIP front-end kernels alone (the projection weights of the handle are never used)"""
+
+    def __init__(self, config, padded_samples=0):
+        import copy
+        cfg = copy.copy(config)
+        cfg.feature_dim, cfg.tpp_levels, cfg.tpp_pooling_type = 64, [1], "max"
+        cfg.melproj_padded_samples, cfg.melproj_normalize, cfg.melproj_weights_path = padded_samples, False, None
+        super().__init__(cfg, weights=(np.zeros((N_MELS, 64), np.float32), np.zeros(64, np.float32)))
+
+
+class Wav2Vec2FeatureExtractor:
+    """feature_extractor.py:6-52.  K1 on the GPU (radad_embed_normalize == the processor's zero_mean_unit_var_norm,
+    feature_extraction_wav2vec2.py:78-97, `padding=True` over equal-length segments), then Wav2Vec2Model with all hidden states,
+    mean of config.wav2vec2_layers_to_use (:35-39)."""
+
+    def __init__(self, config):
+        import torch
+        from transformers import Wav2Vec2Model
+        self.config = config
+        self.device = torch.device(config.device)
+        d = _local_model_dir(config.wav2vec2_model_name, "Wav2Vec2FeatureExtractor")
+        self.do_normalize = bool(_preprocessor_flag(d, "do_normalize", True))
+        self.model = Wav2Vec2Model.from_pretrained(d, local_files_only=True).to(self.device)
+        self.model.eval()
+        self.feature_dim = self.model.config.hidden_size
+        self._front = _FrontEnd(config)
+
+    def _inputs(self, audio_segments):
+        import torch
+        if self.do_normalize:
+            return self._front.normalize_segments(audio_segments)                          # [S, L] on the device
+        L = self._front.segment_length
+        return torch.stack([torch.from_numpy(np.pad(np.asarray(s, np.float32), (0, L - len(s)))) for s in audio_segments]).to(self.device)
+
+    def extract_features(self, audio_segments: List[np.ndarray], move_to_cpu: bool = False):
+        import torch
+        if len(audio_segments) == 0:
+            return []
+        inputs = self._inputs(audio_segments)
+        with torch.no_grad():
+            hidden_states = self.model(inputs, output_hidden_states=True).hidden_states
+            layers = getattr(self.config, "wav2vec2_layers_to_use", None)
+            if layers:
+                features = torch.mean(torch.stack([hidden_states[i] for i in layers]), dim=0)     # :36-39
+            else:
+                features = hidden_states[-1]
+        return [f.cpu() if move_to_cpu else f for f in features]
+
+
+class WhisperFeatureExtractor:
+    """feature_extractor.py:54-115.  K2 on the GPU: every segment zero-padded to 30 s -> log-mel [80, 3000]
+    (feature_extraction_whisper.py:135-168; radad_embed_logmel with padded_samples = 480 000), all segments of a call in one launch
+    (the reference loops, :92), then WhisperModel.encoder -> last_hidden_state [1500, d_model] per segment, on the CPU (:112)."""
+
+    def __init__(self, config):
+        import torch
+        from transformers import WhisperModel
+        self.config = config
+        self.device = torch.device(config.device)
+        d = _local_model_dir(getattr(config, "whisper_model_name", "openai/whisper-small"), "WhisperFeatureExtractor")
+        self.model = WhisperModel.from_pretrained(d, local_files_only=True).to(self.device)
+        self.model.eval()
+        self.feature_dim = int(getattr(self.model.config, "d_model", 768))
+        n_mels = int(_preprocessor_flag(d, "feature_size", N_MELS))
+        if n_mels != N_MELS or int(_preprocessor_flag(d, "n_fft", N_FFT)) != N_FFT or int(_preprocessor_flag(d, "hop_length", FFT_HOP)) != FFT_HOP:
+            raise ValueError("the HIP log-mel front-end is built for n_fft 400 / hop 160 / 80 mel bands (whisper-tiny ... -medium)")
+        self._use_amp = bool(getattr(config, "use_mixed_precision", False)) and self.device.type == "cuda"
+        self._front = _FrontEnd(config, padded_samples=int(_preprocessor_flag(d, "n_samples", 480000)))
+
+    def extract_features(self, segments):
+        import torch
+        if len(segments) == 0:
+            return []
+        mel = self._front.log_mel(segments).transpose(1, 2).contiguous()                    # [S, 80, 3000] on the device
+        feats = []
+        with torch.no_grad(), torch.autocast("cuda", enabled=self._use_amp):
+            for s in range(mel.shape[0]):                                                   # one encoder call per segment, as :92-112
+                hs = self.model.encoder(mel[s:s + 1]).last_hidden_state
+                feats.append(hs.squeeze(0).detach().float().cpu())
+        return feats
+
+
+class WavLMFeatureExtractor:
+    """feature_extractor.py:117-170.  The processor of a WavLM checkpoint is a Wav2Vec2FeatureExtractor whose preprocessor_config
+    says whether it normalises (K1 on the GPU when it does); then WavLMModel -> last_hidden_state per segment, on the CPU (:168)."""
+
+    def __init__(self, config):
+        import torch
+        from transformers import WavLMModel
+        self.config = config
+        self.device = torch.device(config.device)
+        d = _local_model_dir(getattr(config, "wavlm_model_name", "microsoft/wavlm-base-plus"), "WavLMFeatureExtractor")
+        self.do_normalize = bool(_preprocessor_flag(d, "do_normalize", True))
+        self.return_attention_mask = bool(_preprocessor_flag(d, "return_attention_mask", False))
+        self.model = WavLMModel.from_pretrained(d, local_files_only=True).to(self.device)
+        self.model.eval()
+        self.feature_dim = int(getattr(self.model.config, "hidden_size", 768))
+        self._use_amp = bool(getattr(config, "use_mixed_precision", False)) and self.device.type == "cuda"
+        self._front = _FrontEnd(config)
+
+    _inputs = Wav2Vec2FeatureExtractor._inputs
+
+    def extract_features(self, segments):
+        import torch
+        if len(segments) == 0:
+            return []
+        inputs = self._inputs(segments)
+        feats = []
+        with torch.no_grad(), torch.autocast("cuda", enabled=self._use_amp):
+            for s in range(inputs.shape[0]):                                                # per segment, as :148-168
+                mask = torch.ones_like(inputs[s:s + 1], dtype=torch.long) if self.return_attention_mask else None
+                out = self.model(inputs[s:s + 1], attention_mask=mask)
+                feats.append(out.last_hidden_state.squeeze(0).detach().float().cpu())
+        return feats
+
+
 def build_feature_extractor(config):
-    """pipeline.py:54-65.  'melproj' is built natively; the reference's three kinds need pretrained
-    HuggingFace weights that this build does not ship -- plug an object with `.feature_dim` and
-    `.extract_features` into the pipeline instead."""
+    """pipeline.py:54-65, plus 'melproj' (this build's native extractor: front-end + dense frame projection, one fused device
+    path; the default here because the reference's three kinds need a pretrained encoder on the local disk)."""
     kind = getattr(config, "feature_extractor_type", "melproj").lower()
     if kind == "melproj":
         return MelProjectionFeatureExtractor(config)
-    if kind in ("wav2vec2", "whisper", "wavlm"):
-        raise NotImplementedError(
-            f"feature_extractor_type={kind!r} needs the pretrained HuggingFace encoder the reference downloads by "
-            "name (feature_extractor.py:14-15,70-71,131-132); pass your own extractor object to the pipeline.")
+    if kind == "whisper":
+        return WhisperFeatureExtractor(config)
+    if kind == "wavlm":
+        return WavLMFeatureExtractor(config)
+    if kind == "wav2vec2":
+        return Wav2Vec2FeatureExtractor(config)
     raise ValueError(f"Unsupported feature_extractor_type={kind!r} (use 'melproj' | 'wav2vec2' | 'whisper' | 'wavlm').")

@@ -1,7 +1,8 @@
 """ProjectionLayer -- inference forward of the reference's projection.py:8-160 on the GPU.
 
 Parameter names and shapes equal the reference's fused layout (`fuse_attention_ops=True`, config.py:79), so a
-state_dict trained with the reference loads unchanged:
+state_dict trained with the reference loads unchanged (the unfused layout of projection.py:32-47 -- the same layers inside two
+nn.Sequential -- is renamed on load, and written back under those names by a layer configured with fuse_attention_ops=False):
     attention_score [H,D]  attention_final [1,H]  cst_hidden [H,D]  cst_output [D,H]
     weight_sum [H,D]  normalization (LayerNorm H, eps 1e-6)  unified_embedding [O,H]
 forward([B,K,D]) -> [B,O] runs csrc/proj.hip (eval semantics: dropout is the identity).  Training stays in
@@ -36,8 +37,36 @@ class ProjectionLayer(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
                 nn.init.zeros_(m.bias)
         self.to(self.device)
+        # The reference has a second parameter layout (`fuse_attention_ops=False`, projection.py:32-47): the same four Linear layers
+        # inside two nn.Sequential -- attention_score.{0,2}, cst_attention.{0,2}.  The arithmetic is identical (tanh / relu between
+        # them, projection.py:69-76 vs :78-90), so such a state_dict loads here by renaming, and a layer configured that way
+        # writes those names back out (state_dict() round-trips with the reference module of the same configuration).
+        self.fuse_operations = bool(getattr(config, "fuse_attention_ops", True))
+        self._register_load_state_dict_pre_hook(self._rename_unfused_keys)
+        if not self.fuse_operations:
+            self._register_state_dict_hook(self._emit_unfused_keys)
         self._ws = None
         self._fold = None        # (key, w54t [H,H], b54 [H]): W5 (W4 h + b4) + b5 folded once per set of weights
+
+    _UNFUSED = (("attention_score.0.", "attention_score."), ("attention_score.2.", "attention_final."),
+                ("cst_attention.0.", "cst_hidden."), ("cst_attention.2.", "cst_output."))
+
+    @classmethod
+    def _rename_unfused_keys(cls, state_dict, prefix, *args):
+        for old, new in cls._UNFUSED:
+            for leaf in ("weight", "bias"):
+                k = prefix + old + leaf
+                if k in state_dict:
+                    state_dict[prefix + new + leaf] = state_dict.pop(k)
+
+    @classmethod
+    def _emit_unfused_keys(cls, module, state_dict, prefix, local_metadata):
+        for old, new in reversed(cls._UNFUSED):          # (attention_final -> attention_score.2 before attention_score -> .0)
+            for leaf in ("weight", "bias"):
+                k = prefix + new + leaf
+                if k in state_dict:
+                    state_dict[prefix + old + leaf] = state_dict.pop(k)
+        return state_dict
 
     def forward(self, input_embeddings: torch.Tensor) -> torch.Tensor:
         """projection.py:108-117 (eval path).  input [B, top_k, D] -> [B, output_dim]."""

@@ -74,10 +74,10 @@ def write_faiss_flat(path: str, rows: np.ndarray, metric: str):
 
 def knn_options_from_config(config):
     """the optional scan knobs, read the way the reference reads its own optional ones (getattr with a default,
-    vector_database.py:43,67,80): knn_hi_plane, knn_centre, knn_smallq_hi, knn_wide_min_q, knn_dense; absent / None = the library's default"""
+    vector_database.py:43,67,80): knn_hi_plane, knn_centre, knn_smallq_hi, knn_wide_min_q, knn_dense, knn_live_floor; absent / None = the library's default"""
     opts = dict(hi_plane=getattr(config, "knn_hi_plane", None), centre=getattr(config, "knn_centre", None),
                 smallq_hi=getattr(config, "knn_smallq_hi", None), wide_min_q=getattr(config, "knn_wide_min_q", None),
-                dense=getattr(config, "knn_dense", None))
+                dense=getattr(config, "knn_dense", None), live_floor=getattr(config, "knn_live_floor", None))
     return {k: v for k, v in opts.items() if v is not None}
 
 
@@ -87,8 +87,8 @@ class HipFlatIndex:
     is_trained = True   # flat indexes need no training (vector_database.py:124)
 
     def __init__(self, d: int, metric: int, device: int = 0, id_base: int = 0, store_f16: bool = False, hi_plane=None, centre=None,
-                 smallq_hi=None, wide_min_q=None, dense=None):
-        """hi_plane / centre / smallq_hi / wide_min_q / dense: kernel choices of the handle (radad_knn_set_option; None = the library's
+                 smallq_hi=None, wide_min_q=None, dense=None, live_floor=None):
+        """hi_plane / centre / smallq_hi / wide_min_q / dense / live_floor: kernel choices of the handle (radad_knn_set_option; None = the library's
         default).  They change speed, never results: A/B measurements and the parity tests select kernels through them."""
         self._lib = _lib.load()
         self.d = int(d)
@@ -100,9 +100,9 @@ class HipFlatIndex:
         _lib.check(self._lib.radad_knn_create_ex(self.d, self.metric, _lib.STORE_F16 if self.store_f16 else _lib.STORE_F32,
                                                  self.device, self.id_base, C.byref(h)), "radad_knn_create")
         self._h = h
-        self.options = dict(hi_plane=hi_plane, centre=centre, smallq_hi=smallq_hi, wide_min_q=wide_min_q, dense=dense)
+        self.options = dict(hi_plane=hi_plane, centre=centre, smallq_hi=smallq_hi, wide_min_q=wide_min_q, dense=dense, live_floor=live_floor)
         for opt, val in ((_lib.KNN_OPT_HI_PLANE, hi_plane), (_lib.KNN_OPT_CENTRE, centre), (_lib.KNN_OPT_SMALLQ_HI, smallq_hi),
-                         (_lib.KNN_OPT_WIDE_MIN_Q, wide_min_q), (_lib.KNN_OPT_DENSE, dense)):
+                         (_lib.KNN_OPT_WIDE_MIN_Q, wide_min_q), (_lib.KNN_OPT_DENSE, dense), (_lib.KNN_OPT_LIVE_FLOOR, live_floor)):
             if val is not None:
                 _lib.check(self._lib.radad_knn_set_option(self._h, opt, int(val)), "radad_knn_set_option")
 
@@ -256,16 +256,23 @@ class HipFlatIndex:
         _lib.check(self._lib.radad_knn_plane_rebuilds(self._h, C.byref(r)))
         return {"built": bool(b.value), "centred": bool(c.value), "one_scale": bool(o.value), "rebuilds": r.value}
 
+    def tuning_info(self):
+        """{"cap_boost", "fp32_searches_left", "reports_consumed"} (radad_knn_tuning_info): read without synchronising"""
+        a, b, n = C.c_int(), C.c_int(), C.c_int64()
+        _lib.check(self._lib.radad_knn_tuning_info(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return {"cap_boost": a.value, "fp32_searches_left": b.value, "reports_consumed": n.value}
+
     def last_launch(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         _lib.check(self._lib.radad_knn_last_launch(self._h, C.byref(a), C.byref(b), C.byref(c)))
         st, nq = (C.c_int * 6)(), C.c_int64()
         _lib.check(self._lib.radad_knn_last_certificate(self._h, C.byref(nq), st))
-        kind, nl = C.c_int(), C.c_int()
+        kind, nl, nph = C.c_int(), C.c_int(), C.c_int()
         _lib.check(self._lib.radad_knn_last_scan_kind(self._h, C.byref(kind)))
         _lib.check(self._lib.radad_knn_last_scan_launches(self._h, C.byref(nl)))
+        _lib.check(self._lib.radad_knn_last_scan_phases(self._h, C.byref(nph)))
         return {"query_tiles": a.value, "db_splits": b.value, "block_threads": c.value, "rechecked_queries": st[0],
-                "scan_launches": nl.value,
+                "scan_launches": nl.value, "scan_phases": nph.value,
                 "scan_kind": ("f32_tile", "hi_tile", "f32_smallq", "hi_smallq", "f16_tile", "f32_dense")[kind.value],
                 "certificate": {"queries": nq.value, "rejected": st[0], "candidates_rescored": st[1],
                                 "rejected_buffer_full": st[2], "rejected_list_used_up": st[3],

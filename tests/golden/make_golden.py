@@ -104,6 +104,19 @@ def main():
         g[f"proj{D}_seed"] = np.asarray(seed)
         g[f"proj{D}_names"] = np.asarray(list(sd.keys()))
         g[f"proj{D}_x"], g[f"proj{D}_y"] = x.numpy(), y.numpy()
+    # the unfused parameter layout (fuse_attention_ops=False, projection.py:32-47): same arithmetic, nn.Sequential parameter names
+    cfg.fuse_attention_ops = False
+    D, B, seed = 512, 3, 5400
+    layer = ref_projection.ProjectionLayer(cfg, D).eval()
+    sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in layer.state_dict().items()}, seed)
+    layer.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    x = torch.from_numpy(synth.rows(0, B * 5, D, seed + 99).reshape(B, 5, D))
+    with torch.no_grad():
+        y = layer(x)
+    g["projU_seed"], g["projU_names"] = np.asarray(seed), np.asarray(list(sd.keys()))
+    g["projU_shapes"] = np.asarray([",".join(map(str, v.shape)) for v in sd.values()])
+    g["projU_x"], g["projU_y"] = x.numpy(), y.numpy()
+    cfg.fuse_attention_ops = True
     D, seed = 512, 5300
     model = ref_radad.RADADModel(cfg, D).eval()
     sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed)

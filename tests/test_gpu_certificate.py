@@ -368,3 +368,48 @@ def test_small_stores_score_densely(gpu, metric, n, dim):
             od, oi = O.knn(stored, q[:nq], k, metric)
         np.testing.assert_array_equal(I, oi)
         assert a.last_launch()["certificate"]["rejected"] == 0
+
+
+@pytest.mark.parametrize("metric", ["COSINE", "L2"])
+def test_floors_raised_inside_the_launch_equal_the_launch_per_phase_form(gpu, knn_oracle_lib, metric):
+    """Round 5: the tile scan covers a large store in ONE launch whose workgroups raise the admission floors themselves (every
+    workgroup re-reads its floors per tile; after the first eighth of its chunk it takes a few queries, selects the k-th best of the
+    candidates ANY workgroup has emitted so far and raises their floors).  Which candidates a query collects depends on timing;
+    what the search returns must not: same ids, distances and float64 keys as round 4's one launch per phase, == the C oracle.
+    1.3 M rows x 384 (RSC 0 / RSC 3 variants), 700 queries (a ragged last query tile), planted near-duplicates + 40 rows tied around rank k."""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    lib = _lib.load()
+    n, dim, nq, k = 1_300_000, 384, 700, 10
+    rows = torch.empty((n, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(rows.data_ptr(), 0, n, dim, 4321, 0, _lib.stream_ptr(gpu)))
+    q = torch.empty((nq, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(q.data_ptr(), 0, nq, dim, 977, 0, _lib.stream_ptr(gpu)))
+    planted = (torch.arange(nq, device=gpu) * 1801 + 29) % n
+    rows[planted] = q + 0.05 * rows[:nq]
+    for t in range(40):                                  # near-ties around rank k of query 3, spread over the store
+        rows[(t * 31337 + 11) % n] = q[3] + 0.2 * rows[5] + 1e-6 * (t + 1) * rows[6]
+    m = _lib.METRIC_L2 if metric == "L2" else _lib.METRIC_COSINE
+    res = {}
+    for live in (1, 0):
+        idx = HipFlatIndex(dim, m, 0, live_floor=live)
+        idx.add_device(rows)
+        for rep in range(3):                             # (timing differs from run to run: the result must not)
+            D, I, K64 = idx.search_device(q, k, return_f64=True)
+            info = idx.last_launch()
+            assert info["scan_kind"] == "hi_tile" and info["scan_phases"] == 2 and info["scan_launches"] == (1 if live else 2), info
+            assert info["rechecked_queries"] <= 1, info
+            if live in res:
+                assert torch.equal(res[live][1], I) and torch.equal(res[live][2], K64)
+            res[live] = (D, I, K64)
+        if live:
+            stored = idx.reconstruct_batch(torch.arange(0, n, device=gpu)).cpu().numpy() if metric == "COSINE" else rows.cpu().numpy()
+            qn = q
+            if metric == "COSINE":
+                qn = torch.empty_like(q)
+                _lib.check(lib.radad_rownorm(q.data_ptr(), qn.data_ptr(), nq, dim, 0, _lib.stream_ptr(gpu)))
+        del idx
+    assert torch.equal(res[1][1], res[0][1]) and torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][2], res[0][2])
+    sample = np.concatenate([[3], np.arange(0, nq, nq // 24)[:24], [nq - 1]])
+    _sample_check(knn_oracle_lib, stored, qn.cpu().numpy(), res[1][1].cpu().numpy(), res[1][2].cpu().numpy(), k,
+                  "IP" if metric == "COSINE" else "L2", 0, sample)

@@ -45,6 +45,30 @@ def test_projection_matches_reference_golden(gpu, golden_dir, D):
         layer(x)
 
 
+@pytest.mark.parametrize("fuse_here", [True, False])
+def test_projection_loads_the_unfused_parameter_layout(gpu, golden_dir, fuse_here):
+    """projection.py:32-47: with fuse_attention_ops=False the reference keeps the same four Linear layers inside two nn.Sequential
+    (attention_score.{0,2}, cst_attention.{0,2}).  Such a state_dict must load -- into a layer of either configuration -- and give
+    the reference module's output; a layer configured unfused writes those names back."""
+    import torch
+    import radad_retrievalaugmenteddeepfakeaudiodetection_amd as R
+    g = np.load(os.path.join(golden_dir, "projection.npz"))
+    names = [str(n) for n in g["projU_names"]]
+    shapes = {n: tuple(int(v) for v in str(sh).split(",")) for n, sh in zip(names, g["projU_shapes"])}
+    assert "attention_score.2.weight" in names and "cst_attention.0.bias" in names
+    sd = synth.fill_state_dict(shapes, int(g["projU_seed"]))
+    cfg = R.Config()
+    cfg.update(device=gpu, fuse_attention_ops=fuse_here)
+    layer = R.ProjectionLayer(cfg, 512).eval()
+    res = layer.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    assert not res.missing_keys and not res.unexpected_keys
+    with torch.no_grad():
+        y = layer(torch.from_numpy(g["projU_x"]).to(gpu)).cpu().numpy()
+    np.testing.assert_allclose(y, g["projU_y"], rtol=0, atol=1e-4)
+    out_names = list(layer.state_dict().keys())
+    assert sorted(out_names) == (sorted(names) if not fuse_here else sorted(_proj_shapes(512)))
+
+
 def test_projection_fold_cache_and_unfolded_call(gpu):
     """The W5*W4 fold is rebuilt when the weights change (load_state_dict / in-place update), and the C entry point
     gives the same answer when the caller passes no fold (w54t = NULL: folded per call into the workspace)."""

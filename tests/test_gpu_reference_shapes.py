@@ -373,3 +373,35 @@ def test_kth_largest_kernel(gpu):
         want = torch.topk(torch.nan_to_num(x, nan=float("-inf")).permute(1, 0, 2).reshape(nq, G * k), k, dim=1).values[:, k - 1]
         got = HipFlatIndex.global_bound(x.to(gpu), k).cpu()
         assert torch.equal(got, want), (G, nq, k)
+
+
+def test_certificate_reports_are_acted_on_while_the_host_runs_ahead(gpu):
+    """the handle's self-tuning reads the certificate's reports from pinned memory without waiting.  Round 4 acted only on
+    the report of exactly the search two back -- a host that queues searches faster than the device runs them (a bench loop, back to
+    back predict() calls) never saw one and a mostly-rejected store stayed on the exact kernel for every query.  Here: a store whose
+    rows are all within 2 eps of each other (every query overflows its candidate buffer), searches queued WITHOUT any host
+    synchronisation: the handle must retune (wider candidate buffers, then the fp32 kernels) while the queue is running, and the
+    results stay those of the float64 brute force."""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    n, dim, B, k = 40000, 128, 256, 10
+    base = _dev_rows(gpu, 0, 1, dim, 9301)
+    rows = base + 1e-4 * _dev_rows(gpu, 0, n, dim, 9302)
+    q = base + 0.5 * _dev_rows(gpu, 0, B, dim, 9303)
+    idx = HipFlatIndex(dim, _lib.METRIC_L2, gpu.index or 0)
+    idx.add_device(rows)
+    torch.cuda.synchronize()
+    retuned_at = None
+    for i in range(400):
+        D, I = idx.search_device(q, k)                     # (asynchronous: nothing here waits for the device)
+        t = idx.tuning_info()
+        if t["cap_boost"] > 1 or t["fp32_searches_left"] > 0:
+            retuned_at = i
+            break
+    assert retuned_at is not None and t["reports_consumed"] >= 1, t
+    torch.cuda.synchronize()
+    D, I = idx.search_device(q, k)
+    od, oi = O.knn(rows.cpu().numpy(), q.cpu().numpy()[:16], k, "L2")
+    if O.rank_gaps(od).min() > 0:
+        np.testing.assert_array_equal(I[:16].cpu().numpy(), oi)
+    np.testing.assert_allclose(D[:16].cpu().numpy(), od, rtol=1e-5, atol=1e-7)
