@@ -191,6 +191,10 @@ int radad_knn_last_scan_launches(radad_knn_t h, int* n_launches);
 /* phases of the last search's tile scan: 1 + the number of times the admission floors were raised from the candidates emitted so far --
  * inside the one launch (RADAD_KNN_OPT_LIVE_FLOOR, the default: 2 up to ~1.2 M rows, 3 up to ~9.5 M, 4 beyond) or between launches */
 int radad_knn_last_scan_phases(radad_knn_t h, int* n_phases);
+/* Diagnostics of the last search when it was a certified tile scan of nq queries (synchronises with it): per query the number of
+ * candidates the scan emitted (more than the candidate buffer holds -- 1024, 4096 after the handle widened them -- rejects the query)
+ * and, optionally, the admission floor the scan ended with.  Host pointers. */
+int radad_knn_last_emitted(radad_knn_t h, int* counts_host, float* floors_host, int64_t nq);
 /* the f16 plane the certified scans read, once a search has built it: built (0/1); centred = the common component (column mean)
  * of the rows is subtracted before rounding (stores of embeddings that share most of their mean); one_scale = one power-of-two
  * scale for all rows (rows of one magnitude: the scan applies no per-score arithmetic) */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "radad_knn_search_abort": (C.c_int, [C.c_void_p]),
     "radad_knn_last_scan_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_last_scan_phases": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "radad_knn_last_emitted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     "radad_knn_plane_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "radad_knn_plane_rebuilds": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_tuning_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),

@@ -1132,6 +1132,8 @@ constexpr int KNN_CERT_EXTRA = 32;       // candidates beyond k the certified re
 constexpr int KNN_CERT_CAP = 512;        // ... and this many in all: stores of near-duplicates (the benchmark plants 2048 rows
                                          // within 2e-2 of every query) put hundreds of rows within 2 eps of the k-th
 constexpr int KNN_CERT_MAX_K = 128;      // largest k the certificate + exact kernel cover
+constexpr int KNN_PROG_OFF = 64;         // the tile scan's progress counters (one per query tile) sit behind the 256-byte flag_count block ...
+constexpr int KNN_PROG_MAX = 4096;       // ... at most this many query tiles (1 M queries) raise their floors inside one launch
 constexpr int KW_SAMPLE_SPLITS = 64;     // one-tile splits of the threshold pre-pass (<= 16384 rows)
 
 struct RefineParams {
@@ -1282,7 +1284,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_kth_floor(KthParams p) {
 // other workgroups' candidates while they are being written: a slot reserved but not written yet must read as "no entry".
 __global__ __launch_bounds__(RF_THREADS) void k_floor_from_sample(const float* __restrict__ score, const int* __restrict__ idx, int n_ent, int rank,
                                                                  const float* __restrict__ eps, float* __restrict__ thr,
-                                                                 float* __restrict__ clear, int clear_n) {
+                                                                 float* __restrict__ clear, int clear_n, int* __restrict__ zero, int zero_n) {
     extern __shared__ __attribute__((aligned(16))) char smem_f[];
     float* e_sc = reinterpret_cast<float*>(smem_f);                      // [n_ent]
     int* hist = reinterpret_cast<int*>(e_sc + n_ent);                    // [256]
@@ -1291,6 +1293,7 @@ __global__ __launch_bounds__(RF_THREADS) void k_floor_from_sample(const float* _
     for (int i = threadIdx.x; i < n_ent; i += RF_THREADS)
         e_sc[i] = idx[q * n_ent + i] != IDX_SENTINEL ? score[q * n_ent + i] : -INFINITY;
     if (clear) for (int i = threadIdx.x; i < clear_n; i += RF_THREADS) clear[q * clear_n + i] = -INFINITY;
+    if (zero && q == 0) for (int i = threadIdx.x; i < zero_n; i += RF_THREADS) zero[i] = 0;      // (the scan's per-query-tile progress counters)
     const float a = radix_select_kth(e_sc, n_ent, rank, hist, xchg);
     if (threadIdx.x == 0) thr[q] = a > -INFINITY ? a - 2.f * eps[q] : -INFINITY;
 }
@@ -2314,6 +2317,7 @@ struct radad_knn_s {
     int opt_smallq_hi = 1;       // small batches stream the f16 plane (0: the fp32 rows)
     int opt_wide_min_q = 17;     // smallest batch that takes the 256-query tile scan
     int opt_dense = 1;           // stores of <= RF_STAGE_MAX rows: all scores + select (k_knn_dense) instead of the register-list kernels
+    size_t last_o_cnt = 0, last_o_thr = 0; int64_t last_emit_nq = 0;   // the last tile-scan search's candidate counters / floors in the workspace
     int opt_live_floor = 1;      // the tile scan covers the store in ONE launch and raises its admission floors inside it (0: one launch per phase)
     int last_scan_phases = 0;    // (radad_knn_last_scan_phases)
     unsigned* stat = nullptr;    // device [3] float bits: max |y'|, max |y' - yh| (y' = y - mu when the plane is centred, else y) and
@@ -3107,7 +3111,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     const size_t o_thr = off; off += b_vec;
     const size_t o_ak = off; off += b_vec;             // a_k of the candidates (two-half searches: k_kth_floor -> k_merge_refine)
     const size_t o_cnt = off; off += b_vec;            // cand_cnt [nq] int (zeroed by k_hi_rows with the counters)
-    const size_t o_fcount = off; off += 256;           // flag_count + statistics
+    const size_t o_fcount = off; off += 256 + KNN_PROG_MAX * sizeof(int);   // flag_count + statistics | the tile scan's progress counters (one per query tile)
     const size_t o_fsel = off; off += b_vec;
     const size_t o_ps = off; off += b_part;
     const size_t o_pi = off; off += b_part;
@@ -3187,7 +3191,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         wp.cand_cap = emit_cap; wp.cand_cnt = cand_cnt;
         wp.thr_init = nullptr;
         wp.ksplit = 1; wp.kacc = nullptr; wp.kflag = nullptr; wp.loose_floor = 0; wp.chunk_stride = 0;
-        wp.floor_live = nullptr; wp.eps = nullptr; wp.k_sel = 0; wp.refresh_at[0] = wp.refresh_at[1] = wp.refresh_at[2] = wp.refresh_at[3] = 0;
+        wp.floor_live = nullptr; wp.eps = nullptr; wp.k_sel = 0; wp.prog = nullptr; wp.prog_thr[0] = wp.prog_thr[1] = wp.prog_thr[2] = wp.prog_thr[3] = 0;
         wp.debug = 0; wp.stamps = nullptr;
 #ifdef RADAD_DEBUG_HOOKS        // timing experiments only (make exp); never in the shipped library
         { const char* dbg = getenv("RADAD_DEBUG_KNN"); wp.debug = dbg ? atoi(dbg) : 0; }
@@ -3216,14 +3220,11 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         // and its tail, and a 100 k-row store (BASELINE config 2) ran 64 + 327 tiles as 1 + 3 tile times on 512 workgroups.
         int live_nr = 0, live_at[4] = {0, 0, 0, 0};
         const bool one_go = (int64_t)ksel * h->ntotal <= (int64_t)(emit_cap / 3) * s_splits * KW_M;
-        if (!one_go && emit_cap <= 1024 && h->opt_live_floor) {
-            int gq, gs; int64_t gc;
-            knn_geometry_wide(h->ntotal, nq, &gq, &gs, &gc);
-            const int gq_grid = gq <= 8 ? gq : (gq + 7) / 8 * 8;
-            const int64_t streams = std::max<int64_t>(1, std::min<int64_t>(gs, 256 / std::max(1, std::min(gq_grid, 256))));
-            const int64_t c_tiles = gc / KW_M;
-            for (int64_t t = std::max<int64_t>(1, ceil_div64(hi_phase0, (int64_t)KW_M * streams)); t < c_tiles && live_nr < 4; t *= 8)
-                live_at[live_nr++] = (int)t;
+        if (!one_go && emit_cap <= 1024 && h->opt_live_floor && h->dim >= 128 && n_qtiles <= KNN_PROG_MAX) {
+            // refresh when a query tile has started 8 x the sample's tiles, 8 x that, ... (the phases of the launch-per-phase form), as
+            // long as a fifth of the store is still to come
+            const int64_t tiles = ceil_div64(h->ntotal, KW_M);
+            for (int64_t t = hi_phase0 / KW_M; t + KW_REFRESH_WGS <= tiles - tiles / 5 && live_nr < 4; t *= 8) live_at[live_nr++] = (int)t;
         }
         // sample pre-pass: the (k + margin)-th best score over the first rows of the store is a score at least k rows reach, so the
         // scan admits from it (minus 2 eps) instead of -inf (the score of a (row, query) pair does not depend on the tiling).
@@ -3249,7 +3250,8 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             else hipLaunchKernelGGL(k_knn_hi_sample<3>, sg, sb, lds, st, sp);
             const int n_ent = sp.n_splits * KW_SAMPLE_LIST;
             hipLaunchKernelGGL(k_floor_from_sample, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)n_ent * 4 + 1040, st, (const float*)sp.part_score,
-                               (const int*)sp.part_idx, n_ent, k + margin, (const float*)eps, thr_init, live_nr > 0 ? ps : (float*)nullptr, emit_cap);
+                               (const int*)sp.part_idx, n_ent, k + margin, (const float*)eps, thr_init, live_nr > 0 ? ps : (float*)nullptr, emit_cap,
+                               live_nr > 0 ? flag_count + KNN_PROG_OFF : (int*)nullptr, n_qtiles);
             wp.thr_init = thr_init;
         }
         const dim3 b(KW_THREADS);
@@ -3263,7 +3265,8 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             rp.loose_floor = (r0 == 0 && r1 == h->ntotal && s_splits < KW_SAMPLE_SPLITS && live_nr == 0) ? 1 : 0;      // one launch behind a small sample
             if (live_nr > 0) {
                 rp.floor_live = thr_init; rp.eps = eps; rp.k_sel = k;
-                for (int i = 0; i < 4; ++i) rp.refresh_at[i] = live_at[i];
+                for (int i = 0; i < 4; ++i) rp.prog_thr[i] = live_at[i];
+                rp.prog = flag_count + KNN_PROG_OFF;
             }
             int gq, gs; int64_t gc;
             knn_geometry_wide(rp.n, nq, &gq, &gs, &gc);
@@ -3437,6 +3440,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     ctx->small_lists = !use_hi && !dense && (smallq || smallq_hi);
     ctx->canonical = use_hi || smallq_hi || !l2;
     ctx->have_ak = lb_out != nullptr && use_hi && cert; ctx->o_ak = o_ak;
+    h->last_o_cnt = o_cnt; h->last_o_thr = o_thr; h->last_emit_nq = use_hi ? nq : 0;
     ctx->o_eps = o_eps; ctx->o_thr = o_thr; ctx->o_cnt = o_cnt; ctx->o_fcount = o_fcount; ctx->o_fsel = o_fsel; ctx->o_ps = o_ps; ctx->o_pi = o_pi;
     ctx->o_xk = o_xk; ctx->o_xi = o_xi;
     return RADAD_OK;
@@ -3736,6 +3740,17 @@ int radad_knn_plane_rebuilds(radad_knn_t h, int* n_out) {
     RADAD_REQUIRE(h && n_out, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);
     *n_out = h->plane_rebuilds;
+    return RADAD_OK;
+}
+
+int radad_knn_last_emitted(radad_knn_t h, int* counts_host, float* floors_host, int64_t nq) {
+    RADAD_REQUIRE(h && counts_host, "NULL argument");
+    std::lock_guard<std::mutex> lk(h->mu);
+    DeviceGuard g(h->device);
+    RADAD_REQUIRE(h->last_emit_nq > 0 && nq == h->last_emit_nq && h->ws, "radad_knn_last_emitted: the last search of this handle was not a tile scan of %lld queries", (long long)nq);
+    RADAD_HIP_CHECK(knn_wait_last_search(h));
+    RADAD_HIP_CHECK(hipMemcpy(counts_host, (const char*)h->ws + h->last_o_cnt, (size_t)nq * sizeof(int), hipMemcpyDeviceToHost));
+    if (floors_host) RADAD_HIP_CHECK(hipMemcpy(floors_host, (const char*)h->ws + h->last_o_thr, (size_t)nq * sizeof(float), hipMemcpyDeviceToHost));
     return RADAD_OK;
 }
 

@@ -256,6 +256,13 @@ class HipFlatIndex:
         _lib.check(self._lib.radad_knn_plane_rebuilds(self._h, C.byref(r)))
         return {"built": bool(b.value), "centred": bool(c.value), "one_scale": bool(o.value), "rebuilds": r.value}
 
+    def last_emitted(self, nq: int):
+        """(candidates emitted per query int32 [nq], final admission floors float32 [nq]) of the last tile-scan search (radad_knn_last_emitted)"""
+        c = np.empty(nq, np.int32)
+        f = np.empty(nq, np.float32)
+        _lib.check(self._lib.radad_knn_last_emitted(self._h, c.ctypes.data, f.ctypes.data, int(nq)), "radad_knn_last_emitted")
+        return c, f
+
     def tuning_info(self):
         """{"cap_boost", "fp32_searches_left", "reports_consumed"} (radad_knn_tuning_info): read without synchronising"""
         a, b, n = C.c_int(), C.c_int(), C.c_int64()

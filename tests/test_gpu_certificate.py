@@ -399,8 +399,9 @@ def test_floors_raised_inside_the_launch_equal_the_launch_per_phase_form(gpu, kn
             info = idx.last_launch()
             assert info["scan_kind"] == "hi_tile" and info["scan_phases"] == 2 and info["scan_launches"] == (1 if live else 2), info
             assert info["rechecked_queries"] <= 1, info
-            if live in res:
-                assert torch.equal(res[live][1], I) and torch.equal(res[live][2], K64)
+            if live in res:      # (a query the certificate rejects in one run and not in the other gets its float64 key from the exact
+                                 # kernel, which sums in another order: keys agree to the last bits, ids exactly)
+                assert torch.equal(res[live][1], I) and torch.allclose(res[live][2], K64, rtol=1e-13, atol=1e-13)
             res[live] = (D, I, K64)
         if live:
             stored = idx.reconstruct_batch(torch.arange(0, n, device=gpu)).cpu().numpy() if metric == "COSINE" else rows.cpu().numpy()
@@ -409,7 +410,7 @@ def test_floors_raised_inside_the_launch_equal_the_launch_per_phase_form(gpu, kn
                 qn = torch.empty_like(q)
                 _lib.check(lib.radad_rownorm(q.data_ptr(), qn.data_ptr(), nq, dim, 0, _lib.stream_ptr(gpu)))
         del idx
-    assert torch.equal(res[1][1], res[0][1]) and torch.equal(res[1][0], res[0][0]) and torch.equal(res[1][2], res[0][2])
+    assert torch.equal(res[1][1], res[0][1]) and torch.equal(res[1][0], res[0][0]) and torch.allclose(res[1][2], res[0][2], rtol=1e-13, atol=1e-13)
     sample = np.concatenate([[3], np.arange(0, nq, nq // 24)[:24], [nq - 1]])
     _sample_check(knn_oracle_lib, stored, qn.cpu().numpy(), res[1][1].cpu().numpy(), res[1][2].cpu().numpy(), k,
                   "IP" if metric == "COSINE" else "L2", 0, sample)
