@@ -1298,6 +1298,38 @@ __global__ __launch_bounds__(RF_THREADS) void k_floor_from_sample(const float* _
     if (threadIdx.x == 0) thr[q] = a > -INFINITY ? a - 2.f * eps[q] : -INFINITY;
 }
 
+// the same for samples of <= 1024 entries (every search of the tile scan: 64 sample tiles x 16): ONE WAVE per query, the entries in
+// registers (16 per lane), the rank-th largest by a 32-step binary search on the keys with ballot counts -- no LDS, no barriers, no LDS
+// atomics (the radix select's histogram passes were 11.6 us of every search for 1024 queries; ds_add retires about a lane per cycle).
+__global__ __launch_bounds__(RF_THREADS) void k_floor_from_sample_w(const float* __restrict__ score, const int* __restrict__ idx, int n_ent, int rank,
+                                                                   const float* __restrict__ eps, float* __restrict__ thr, int64_t nq,
+                                                                   float* __restrict__ clear, int clear_n, int* __restrict__ zero, int zero_n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * (RF_THREADS / 64) + (threadIdx.x >> 6);
+    if (zero && blockIdx.x == 0) for (int i = threadIdx.x; i < zero_n; i += RF_THREADS) zero[i] = 0;
+    if (q >= nq) return;                                                 // (wave-uniform)
+    unsigned key[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i = lane + 64 * j;
+        float v = -INFINITY;
+        if (i < n_ent && idx[q * n_ent + i] != IDX_SENTINEL) v = score[q * n_ent + i];
+        const unsigned u = __float_as_uint(v);
+        key[j] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
+    if (clear) for (int i = lane; i < clear_n; i += 64) clear[q * clear_n + i] = -INFINITY;
+    unsigned cur = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned t = cur | (1u << bit);
+        int n = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) n += __popcll(__ballot(key[j] >= t));
+        if (n >= rank) cur = t;
+    }
+    const float a = __uint_as_float((cur & 0x80000000u) ? (cur & 0x7fffffffu) : ~cur);      // -inf when fewer than `rank` entries exist
+    if (lane == 0) thr[q] = a > -INFINITY ? a - 2.f * eps[q] : -INFINITY;
+}
+
 template <bool STAGED>
 __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_m[];
@@ -2648,7 +2680,19 @@ static void knn_geometry_wide(int64_t n, int64_t nq, int* n_qtiles, int* n_split
     want = std::min<int64_t>(want, tiles);
     want = std::max<int64_t>(8, ceil_div64(want, 8) * 8);
     want = std::min<int64_t>(want, 1024);
-    const int64_t tiles_per = ceil_div64(tiles, want);
+    int64_t tiles_per = ceil_div64(tiles, want);
+    // Two rounds of workgroups are as good as one only while the chunks are long: a launch takes (rounds of 256 workgroups) x (tiles
+    // per chunk) tile times, and with a handful of tiles per chunk the rounding of the second factor decides -- BASELINE config 2's
+    // 100 k rows are 391 tiles x 4 query tiles: 128 chunks of 4 tiles = 392 workgroups = 2 rounds x 4 = 8 tile times, 64 chunks of 7 =
+    // 224 workgroups = ONE round of 7 (1 M rows: 2 x 31 = 1 x 62, the two-round form stays).  One round is taken when it is
+    // strictly cheaper by that count.
+    if (qt <= 256) {
+        auto cost = [&](int64_t splits, int64_t per) { return ceil_div64((int64_t)qt * ceil_div64(tiles, per), 256) * per; };
+        int64_t one = std::max<int64_t>(8, (256 / qt) / 8 * 8);
+        one = std::min<int64_t>(one, want);
+        const int64_t per_one = ceil_div64(tiles, one);
+        if (one < want && cost(one, per_one) < cost(want, tiles_per)) { want = one; tiles_per = per_one; }
+    }
     *n_qtiles = qt;
     *n_splits = (int)want;
     *chunk_rows = tiles_per * KW_M;
@@ -3012,6 +3056,11 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             int64_t want = (tiles * 3 / 100 + 4) / 8 * 8;
             const int64_t need = ((int64_t)(2 * ksel + KW_SAMPLE_LIST - 1) / KW_SAMPLE_LIST + 7) / 8 * 8;
             want = std::max<int64_t>(std::max<int64_t>(want, need), 8);
+            // ... but never fewer tiles than fill ONE round of the chip: the pre-pass is one tile per workgroup, its time is that one
+            // tile's latency whether 32 or 256 workgroups run it, and a larger sample is a tighter first floor (BASELINE config 2's
+            // 100 k rows took 8 tiles = 2048 rows: every tile of the scan's first layer then admitted ~2 rows per query -- 512 returning
+            // atomics per workgroup and tile; with 48 tiles the whole store is one launch behind the sample's floor alone)
+            want = std::max<int64_t>(want, std::min<int64_t>(KW_SAMPLE_SPLITS, (256 / std::max(1, std::min(wq, 256))) / 8 * 8));
             s_splits = (int)std::min<int64_t>(std::min<int64_t>(KW_SAMPLE_SPLITS, want), tiles / 8 / 8 * 8);
         }
         if (s_splits >= 8 && s_splits * KW_SAMPLE_LIST >= 2 * ksel) {
@@ -3084,7 +3133,9 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
     // (dense: eps of exact fp32 products is ~1e-6 of |q||y| -- hardly a row beyond the k best is within 2 eps; k + 32 candidates keep
     // the re-rank's workgroup at 34 KB of LDS for 4096 staged scores, four per CU instead of three: the IVF coarse step's 1024
     // workgroups in one round.  More near-ties than that reject the query: exact kernel.)
-    const int cap = cert ? (dense ? k + KNN_CERT_EXTRA : std::max(k + KNN_CERT_EXTRA, KNN_CERT_CAP)) : ksel;
+    // (a handle that has widened its candidate buffers -- cap_boost: a store whose rows crowd within 2 eps of the k-th best -- also
+    // re-ranks four times as many: the fp32 funnel in front of the float64 re-score takes them at ~2 KB of row reads each)
+    const int cap = cert ? (dense ? k + KNN_CERT_EXTRA : std::max(k + KNN_CERT_EXTRA, KNN_CERT_CAP * (use_hi ? h->cap_boost : 1))) : ksel;
     const int xgroup = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(64 * 1024) / ((size_t)h->dim * 4)));
 
     // ---- workspace: qf (decoded bf16) | qn (normalised) | qh (f16 queries) | qscale | qconst | eps | thr_init | cand_cnt |
@@ -3249,9 +3300,14 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             else if (rsc == 2) hipLaunchKernelGGL(k_knn_hi_sample<2>, sg, sb, lds, st, sp);
             else hipLaunchKernelGGL(k_knn_hi_sample<3>, sg, sb, lds, st, sp);
             const int n_ent = sp.n_splits * KW_SAMPLE_LIST;
-            hipLaunchKernelGGL(k_floor_from_sample, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)n_ent * 4 + 1040, st, (const float*)sp.part_score,
-                               (const int*)sp.part_idx, n_ent, k + margin, (const float*)eps, thr_init, live_nr > 0 ? ps : (float*)nullptr, emit_cap,
-                               live_nr > 0 ? flag_count + KNN_PROG_OFF : (int*)nullptr, n_qtiles);
+            if (n_ent <= 1024)
+                hipLaunchKernelGGL(k_floor_from_sample_w, dim3((unsigned)ceil_div64(nq, RF_THREADS / 64)), dim3(RF_THREADS), 0, st, (const float*)sp.part_score,
+                                   (const int*)sp.part_idx, n_ent, k + margin, (const float*)eps, thr_init, nq, live_nr > 0 ? ps : (float*)nullptr, emit_cap,
+                                   live_nr > 0 ? flag_count + KNN_PROG_OFF : (int*)nullptr, n_qtiles);
+            else
+                hipLaunchKernelGGL(k_floor_from_sample, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)n_ent * 4 + 1040, st, (const float*)sp.part_score,
+                                   (const int*)sp.part_idx, n_ent, k + margin, (const float*)eps, thr_init, live_nr > 0 ? ps : (float*)nullptr, emit_cap,
+                                   live_nr > 0 ? flag_count + KNN_PROG_OFF : (int*)nullptr, n_qtiles);
             wp.thr_init = thr_init;
         }
         const dim3 b(KW_THREADS);

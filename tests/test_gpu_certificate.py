@@ -414,3 +414,40 @@ def test_floors_raised_inside_the_launch_equal_the_launch_per_phase_form(gpu, kn
     sample = np.concatenate([[3], np.arange(0, nq, nq // 24)[:24], [nq - 1]])
     _sample_check(knn_oracle_lib, stored, qn.cpu().numpy(), res[1][1].cpu().numpy(), res[1][2].cpu().numpy(), k,
                   "IP" if metric == "COSINE" else "L2", 0, sample)
+
+
+def test_mass_rejection_is_retuned_inside_the_first_large_search(gpu, knn_oracle_lib):
+    """A store whose rows crowd around the k-th best of EVERY query (the queries are within cos 0.99 of each other and the store holds
+    a near-duplicate of each: BASELINE config 4 built from synthetic clips) overflows the scan's 1024-entry candidate buffers for most
+    of the batch.  The exact float64 kernel would then search most of the batch again -- 10 s at 10 240 queries x 10 M rows -- and a
+    host that queues searches sees no report before it has queued them all.  The first large tile-scan search therefore looks at its
+    own certificate before the exact pass and, when more than a quarter of the batch was rejected, widens the buffers (and the re-rank)
+    and runs again at once.  Results: the float64 brute force, as ever."""
+    import torch
+    from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
+    lib = _lib.load()
+    n, dim, nq, k = 1_000_000, 512, 1024, 10
+    rows = torch.empty((n, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(rows.data_ptr(), 0, n, dim, 4321, 0, _lib.stream_ptr(gpu)))
+    base = torch.empty((1, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(base.data_ptr(), 0, 1, dim, 31, 0, _lib.stream_ptr(gpu)))
+    noise = torch.empty((nq + 1500, dim), device=gpu)
+    _lib.check(lib.radad_synth_rows(noise.data_ptr(), 0, nq + 1500, dim, 32, 0, _lib.stream_ptr(gpu)))
+    q = base + 0.10 * noise[:nq]                                   # queries within cos ~0.99 of each other
+    crowd = (torch.arange(1500, device=gpu) * 653 + 7) % n
+    rows[crowd] = base + 0.10 * noise[nq:]                         # ... and 1500 rows of the same family: a plateau under every query
+    idx = HipFlatIndex(dim, _lib.METRIC_COSINE, 0)
+    idx.add_device(rows)
+    assert idx.tuning_info()["cap_boost"] == 1
+    D, I, K64 = idx.search_device(q, k, return_f64=True)
+    info, tune = idx.last_launch(), idx.tuning_info()
+    assert tune["cap_boost"] == 4, (tune, info)                     # retuned INSIDE the first search ...
+    assert info["scan_kind"] == "hi_tile" and info["rechecked_queries"] <= nq // 20, info      # ... whose final attempt is certified
+    emitted, _ = idx.last_emitted(nq)
+    assert emitted.max() > 1024                                     # (the plateau does not fit the default buffers)
+    qn = torch.empty_like(q)
+    _lib.check(lib.radad_rownorm(q.data_ptr(), qn.data_ptr(), nq, dim, 0, _lib.stream_ptr(gpu)))
+    stored = idx.reconstruct_batch(torch.arange(0, n, device=gpu)).cpu().numpy()
+    _sample_check(knn_oracle_lib, stored, qn.cpu().numpy(), I.cpu().numpy(), K64.cpu().numpy(), k, "IP", 0, np.arange(0, nq, 43)[:24])
+    D2, I2 = idx.search_device(q, k)                                # steady state: no further retune, same answer
+    assert torch.equal(I, I2) and idx.tuning_info()["cap_boost"] == 4
