@@ -118,9 +118,9 @@ def main():
     ap.add_argument("--logmel", choices=["fft", "gemm"], default="fft",
                     help="fft = the shared-frame log-mel as a radix FFT on the vector ALU (k_logmel_fft_clip, default); gemm = the round-3 "
                          "DFT-as-GEMM on the f16 matrix pipe (k_logmel_h_clip), for A/B")
-    ap.add_argument("--live-floor", type=int, choices=[0, 1], default=1,
-                    help="1 (default) = the tile scan covers the store in ONE launch and raises its admission floors inside it; "
-                         "0 = round 4's one launch per phase with k_kth_floor between them, for A/B")
+    ap.add_argument("--live-floor", type=int, choices=[0, 1], default=0,
+                    help="0 (default) = the tile scan runs one launch per phase with k_kth_floor between them; 1 = ONE launch that raises its "
+                         "admission floors inside it (round 5; measured 1-4 %% slower: gpurun_out/r5_ab*.txt), for A/B")
     ap.add_argument("--store-dtype", choices=["f32", "f16"], default="f32",
                     help="f16 = the reference's use_float16 knob (fp16 rows); NOT the headline configuration")
     ap.add_argument("--embed-dtype", choices=["f32", "bf16"], default="f32",
@@ -274,7 +274,7 @@ def main():
     cfg = R.Config()
     cfg.update(device=dev, tpp_levels=[1], tpp_pooling_type="max", feature_dim=DIM, vector_db_index_type="IP",
                use_float16=(args.store_dtype == "f16"), knn_hi_plane=(False if args.scan == "f32" else None),
-               melproj_logmel_fft=(args.logmel == "fft"), knn_live_floor=(None if args.live_floor else 0))
+               melproj_logmel_fft=(args.logmel == "fft"), knn_live_floor=(1 if args.live_floor else None))
     fe = R.MelProjectionFeatureExtractor(cfg)
     B = args.clips
     n_total = args.db_rows

@@ -89,8 +89,8 @@ int radad_knn_create_ex(int dim, int metric, int store_dtype, int device, int64_
  *   RADAD_KNN_OPT_WIDE_MIN_Q smallest batch that takes the 256-query tile scan instead of the streaming kernels (default 17)
  *   RADAD_KNN_OPT_DENSE      1 (default) / 0: an fp32 store of <= 6144 rows (<= 16384 for <= 16 queries) is searched by writing out every
  *                            score and selecting on them / by the register-list kernels
- *   RADAD_KNN_OPT_LIVE_FLOOR 1 (default) / 0: the certified tile scan covers the store in ONE launch and raises its admission floors inside
- *                            it / in one launch per phase with a floor kernel between them (round 4's form)
+ *   RADAD_KNN_OPT_LIVE_FLOOR 0 (default) / 1: the certified tile scan covers the store in one launch per phase with a floor kernel between
+ *                            them / in ONE launch that raises its admission floors inside it (built and measured in round 5: 1-4 % slower)
  * The environment variables RADAD_KNN_HI, RADAD_KNN_CENTRE, RADAD_KNN_SMALLQ_HI, RADAD_WIDE_MIN_Q override the DEFAULTS of handles
  * created while they are set (announced once per process on stderr); the product path never needs them. */
 #define RADAD_KNN_OPT_HI_PLANE 0
@@ -189,7 +189,7 @@ int radad_knn_last_scan_kind(radad_knn_t h, int* kind);
  * sample's admission floor, the rest with the floor the first eighth's candidates give); radad_knn_profile_read has one entry each */
 int radad_knn_last_scan_launches(radad_knn_t h, int* n_launches);
 /* phases of the last search's tile scan: 1 + the number of times the admission floors were raised from the candidates emitted so far --
- * inside the one launch (RADAD_KNN_OPT_LIVE_FLOOR, the default: 2 up to ~1.2 M rows, 3 up to ~9.5 M, 4 beyond) or between launches */
+ * between launches (the default: 2 up to ~1.2 M rows, 3 up to ~9.5 M, 4 beyond) or inside the one launch (RADAD_KNN_OPT_LIVE_FLOOR 1) */
 int radad_knn_last_scan_phases(radad_knn_t h, int* n_phases);
 /* Diagnostics of the last search when it was a certified tile scan of nq queries (synchronises with it): per query the number of
  * candidates the scan emitted (more than the candidate buffer holds -- 1024, 4096 after the handle widened them -- rejects the query)

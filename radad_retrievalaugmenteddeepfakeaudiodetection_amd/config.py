@@ -66,7 +66,7 @@ class Config:
         self.knn_smallq_hi = None           # False: batches of <= 16 queries stream the fp32 rows
         self.knn_wide_min_q = None          # smallest batch on the 256-query tile scan (default 17)
         self.knn_dense = None               # 0: fp32 stores of a few thousand rows stay on the register-list kernels
-        self.knn_live_floor = None          # 0: the tile scan runs one launch per phase (round 4) instead of one launch that raises its floors
+        self.knn_live_floor = None          # 1: the tile scan runs ONE launch that raises its floors inside it (default: one launch per phase)
 
     def update(self, **kwargs):
         """config.py:109-115."""

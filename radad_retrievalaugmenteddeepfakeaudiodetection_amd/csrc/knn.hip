@@ -2350,7 +2350,11 @@ struct radad_knn_s {
     int opt_wide_min_q = 17;     // smallest batch that takes the 256-query tile scan
     int opt_dense = 1;           // stores of <= RF_STAGE_MAX rows: all scores + select (k_knn_dense) instead of the register-list kernels
     size_t last_o_cnt = 0, last_o_thr = 0; int64_t last_emit_nq = 0;   // the last tile-scan search's candidate counters / floors in the workspace
-    int opt_live_floor = 1;      // the tile scan covers the store in ONE launch and raises its admission floors inside it (0: one launch per phase)
+    int opt_live_floor = 0;      // 1: the tile scan covers the store in ONE launch and raises its admission floors inside it; 0 (default): one
+                                 // launch per phase.  Measured on one box, three alternations (gpurun_out/r5_ab*.txt): the one-launch form is
+                                 // 1 % slower in the scan at 1 M x 512 (0.862-0.872 against 0.853-0.860 ms; the step equal within noise: it
+                                 // saves k_kth_floor), 1.4 % at 10 M x 512, 4 % at 50 M x 256 -- ~0.2-0.3 us per tile for the progress atomic
+                                 // and the floor reload, which go to memory past the L2s; the ramps and tails it removes are smaller than that
     int last_scan_phases = 0;    // (radad_knn_last_scan_phases)
     unsigned* stat = nullptr;    // device [3] float bits: max |y'|, max |y' - yh| (y' = y - mu when the plane is centred, else y) and
                                  // max |y| over rows [0, stat_rows)
