@@ -274,7 +274,7 @@ def main():
     cfg = R.Config()
     cfg.update(device=dev, tpp_levels=[1], tpp_pooling_type="max", feature_dim=DIM, vector_db_index_type="IP",
                use_float16=(args.store_dtype == "f16"), knn_hi_plane=(False if args.scan == "f32" else None),
-               melproj_logmel_fft=(args.logmel == "fft"), knn_live_floor=(1 if args.live_floor else None))
+               melproj_logmel_fft=(args.logmel == "fft"), knn_live_floor=(args.live_floor if args.live_floor else None))
     fe = R.MelProjectionFeatureExtractor(cfg)
     B = args.clips
     n_total = args.db_rows

@@ -3275,7 +3275,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
         // and its tail, and a 100 k-row store (BASELINE config 2) ran 64 + 327 tiles as 1 + 3 tile times on 512 workgroups.
         int live_nr = 0, live_at[4] = {0, 0, 0, 0};
         const bool one_go = (int64_t)ksel * h->ntotal <= (int64_t)(emit_cap / 3) * s_splits * KW_M;
-        if (!one_go && emit_cap <= 1024 && h->opt_live_floor && h->dim >= 128 && n_qtiles <= KNN_PROG_MAX) {
+        if (!one_go && emit_cap <= 1024 && h->opt_live_floor == 1 && h->dim >= 128 && n_qtiles <= KNN_PROG_MAX) {
             // refresh when a query tile has started 8 x the sample's tiles, 8 x that, ... (the phases of the launch-per-phase form), as
             // long as a fifth of the store is still to come
             const int64_t tiles = ceil_div64(h->ntotal, KW_M);
@@ -3323,6 +3323,8 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             rp.rbias = wp.rbias ? wp.rbias + r0 : nullptr;
             rp.n = r1 - r0; rp.id_off = r0;
             rp.loose_floor = (r0 == 0 && r1 == h->ntotal && s_splits < KW_SAMPLE_SPLITS && live_nr == 0) ? 1 : 0;      // one launch behind a small sample
+            // (the counting form for the FIRST phase of a large store -- its floor is the sample's, ~64 candidates per tile -- was measured
+            // too: 0.883-0.887 against 0.874-0.877 ms per search, three alternations on one box, gpurun_out/r5_ab.txt of that run: no)
             if (live_nr > 0) {
                 rp.floor_live = thr_init; rp.eps = eps; rp.k_sel = k;
                 for (int i = 0; i < 4; ++i) rp.prog_thr[i] = live_at[i];

@@ -271,11 +271,12 @@ def _preprocessor_flag(model_dir, key, default):
 class _FrontEnd(MelProjectionFeatureExtractor):
     """the HIP front-end kernels alone (the projection weights of the handle are never used)"""
 
-    def __init__(self, config, padded_samples=0):
+    def __init__(self, config, padded_samples=0, normalize=False):
         import copy
         cfg = copy.copy(config)
         cfg.feature_dim, cfg.tpp_levels, cfg.tpp_pooling_type = 64, [1], "max"
-        cfg.melproj_padded_samples, cfg.melproj_normalize, cfg.melproj_weights_path = padded_samples, False, None
+        # normalize: K1 (zero-mean / unit-variance per segment) for the wav2vec2 / WavLM front-end; the Whisper processor does not normalise
+        cfg.melproj_padded_samples, cfg.melproj_normalize, cfg.melproj_weights_path = padded_samples, bool(normalize), None
         super().__init__(cfg, weights=(np.zeros((N_MELS, 64), np.float32), np.zeros(64, np.float32)))
 
 
@@ -294,7 +295,7 @@ class Wav2Vec2FeatureExtractor:
         self.model = Wav2Vec2Model.from_pretrained(d, local_files_only=True).to(self.device)
         self.model.eval()
         self.feature_dim = self.model.config.hidden_size
-        self._front = _FrontEnd(config)
+        self._front = _FrontEnd(config, normalize=True)
 
     def _inputs(self, audio_segments):
         import torch
@@ -367,7 +368,7 @@ class WavLMFeatureExtractor:
         self.model.eval()
         self.feature_dim = int(getattr(self.model.config, "hidden_size", 768))
         self._use_amp = bool(getattr(config, "use_mixed_precision", False)) and self.device.type == "cuda"
-        self._front = _FrontEnd(config)
+        self._front = _FrontEnd(config, normalize=True)
 
     _inputs = Wav2Vec2FeatureExtractor._inputs
 

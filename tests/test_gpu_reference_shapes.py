@@ -379,14 +379,17 @@ def test_certificate_reports_are_acted_on_while_the_host_runs_ahead(gpu):
     """the handle's self-tuning reads the certificate's reports from pinned memory without waiting.  Round 4 acted only on
     the report of exactly the search two back -- a host that queues searches faster than the device runs them (a bench loop, back to
     back predict() calls) never saw one and a mostly-rejected store stayed on the exact kernel for every query.  Here: a store whose
-    rows are all within 2 eps of each other (every query overflows its candidate buffer), searches queued WITHOUT any host
+    rows are within 2 eps of each other cluster by cluster (every query overflows its candidate buffer), searches queued WITHOUT any host
     synchronisation: the handle must retune (wider candidate buffers, then the fp32 kernels) while the queue is running, and the
     results stay those of the float64 brute force."""
     import torch
     from radad_retrievalaugmenteddeepfakeaudiodetection_amd import HipFlatIndex, _lib
     n, dim, B, k = 40000, 128, 256, 10
     base = _dev_rows(gpu, 0, 1, dim, 9301)
-    rows = base + 1e-4 * _dev_rows(gpu, 0, n, dim, 9302)
+    # two tight clusters at +base and -base: the column mean is ~0, so the plane is NOT centred and the bound scales with |y| = |base|,
+    # while the 20 000 rows of a query's own cluster differ by 1e-4: all of them are within 2 eps of its k-th best
+    sign = (torch.arange(n, device=gpu) % 2).float()[:, None] * 2.0 - 1.0
+    rows = sign * base + 1e-4 * _dev_rows(gpu, 0, n, dim, 9302)
     q = base + 0.5 * _dev_rows(gpu, 0, B, dim, 9303)
     idx = HipFlatIndex(dim, _lib.METRIC_L2, gpu.index or 0)
     idx.add_device(rows)

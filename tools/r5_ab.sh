@@ -5,8 +5,8 @@ cd "$(dirname "$0")/.."
 out=gpurun_out/r5_ab.txt
 : > $out
 for i in 1 2 3; do
-  for lf in 1 0; do
-    for rows in 1000000 100000; do
+  for lf in ${LFS:-1 0}; do
+    for rows in ${ROWS:-1000000 100000}; do
       python bench.py --steps 60 --warmup 10 --db-rows $rows --live-floor $lf --sustain 0 --pcie 0 --unstructured 0 --cpu-sample 0 --cpu-baseline-clips 0 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']
