@@ -134,7 +134,8 @@ class MelProjectionFeatureExtractor:
         _lib.require_cuda(wave, "wave")
         if wave.dtype == torch.int16:
             # 16-bit PCM as the audio files hold it: sample / 32768 on the device (what librosa.load returns), into a buffer this
-            # extractor keeps -- an upload of the PCM moves half the bytes of the float samples over PCIe
+            # extractor keeps -- an upload of the PCM moves half the bytes of the float samples over PCIe.  (ONE buffer per extractor:
+            # int16 batches of one extractor must be issued on one stream at a time, like everything else of a handle.)
             pcm = wave.contiguous()
             if getattr(self, "_pcm_f32", None) is None or self._pcm_f32.numel() < pcm.numel() or self._pcm_f32.device != pcm.device:
                 self._pcm_f32 = torch.empty(pcm.numel(), device=pcm.device, dtype=torch.float32)
@@ -154,14 +155,22 @@ class MelProjectionFeatureExtractor:
             if n_clips < 0:
                 raise ValueError("clip_offsets must hold at least one entry")
             # device offsets cannot be checked here without a synchronisation: the plan kernel clamps them (no out-of-bounds
-            # read whatever the tensor holds) and flags what it repaired.  Earlier batches that have COMPLETED are reported here
-            # without waiting (a caller may queue batches back to back); check_device_plan() after the last batch waits for the rest
-            self.check_device_plan(what="an earlier device-offset batch", wait=False)
+            # read whatever the tensor holds) and flags what it repaired.  THIS batch is enqueued first; then earlier batches that have
+            # COMPLETED are reported without waiting (a caller may queue batches back to back) -- the exception names them as earlier
+            # ones and carries this call's output (`.result`), so a valid batch is never lost to another batch's offsets;
+            # check_device_plan() after the last batch waits for the rest
             out = torch.empty((n_clips, self.output_dim), device=wave.device, dtype=out_dtype)
             with torch.cuda.device(wave.device):
                 _lib.check(self._lib.radad_embed_forward_dev(self._h, wave.data_ptr(), offs.data_ptr(), n_clips, wave.numel(),
                                                              out.data_ptr(), code, _lib.stream_ptr(wave.device)),
                            "radad_embed_forward_dev")
+            self._dev_batches = getattr(self, "_dev_batches", 0) + 1
+            try:
+                self.check_device_plan(what=f"an earlier device-offset batch (before batch #{self._dev_batches} of this extractor, which HAS "
+                                            "been enqueued: its output is this exception's .result)", wait=False)
+            except ValueError as e:
+                e.result = out
+                raise
             return out
         offs = np.ascontiguousarray(np.asarray(clip_offsets, np.int64))
         n_clips = len(offs) - 1

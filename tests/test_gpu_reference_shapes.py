@@ -338,8 +338,9 @@ def test_device_offsets_outside_the_wave_buffer_are_clamped_and_reported(gpu):
     bad = torch.tensor([0, n, 2 * n, 3 * n, 40 * n], device=gpu, dtype=torch.int64)
     fe.embed_clips(wave, bad)
     torch.cuda.synchronize()
-    with pytest.raises(ValueError, match="an earlier device-offset batch"):
+    with pytest.raises(ValueError, match="an earlier device-offset batch") as ei:
         fe.embed_clips(wave, good)
+    assert torch.equal(ei.value.result, ref)                           # the valid batch of the raising call WAS enqueued: nothing is lost
     out = fe.embed_clips(wave, good)
     fe.check_device_plan()
     assert torch.equal(out, ref)
