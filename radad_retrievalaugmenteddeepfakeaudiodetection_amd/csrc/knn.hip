@@ -1298,37 +1298,9 @@ __global__ __launch_bounds__(RF_THREADS) void k_floor_from_sample(const float* _
     if (threadIdx.x == 0) thr[q] = a > -INFINITY ? a - 2.f * eps[q] : -INFINITY;
 }
 
-// the same for samples of <= 1024 entries (every search of the tile scan: 64 sample tiles x 16): ONE WAVE per query, the entries in
-// registers (16 per lane), the rank-th largest by a 32-step binary search on the keys with ballot counts -- no LDS, no barriers, no LDS
-// atomics (the radix select's histogram passes were 11.6 us of every search for 1024 queries; ds_add retires about a lane per cycle).
-__global__ __launch_bounds__(RF_THREADS) void k_floor_from_sample_w(const float* __restrict__ score, const int* __restrict__ idx, int n_ent, int rank,
-                                                                   const float* __restrict__ eps, float* __restrict__ thr, int64_t nq,
-                                                                   float* __restrict__ clear, int clear_n, int* __restrict__ zero, int zero_n) {
-    const int lane = threadIdx.x & 63;
-    const int64_t q = (int64_t)blockIdx.x * (RF_THREADS / 64) + (threadIdx.x >> 6);
-    if (zero && blockIdx.x == 0) for (int i = threadIdx.x; i < zero_n; i += RF_THREADS) zero[i] = 0;
-    if (q >= nq) return;                                                 // (wave-uniform)
-    unsigned key[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int i = lane + 64 * j;
-        float v = -INFINITY;
-        if (i < n_ent && idx[q * n_ent + i] != IDX_SENTINEL) v = score[q * n_ent + i];
-        const unsigned u = __float_as_uint(v);
-        key[j] = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    }
-    if (clear) for (int i = lane; i < clear_n; i += 64) clear[q * clear_n + i] = -INFINITY;
-    unsigned cur = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned t = cur | (1u << bit);
-        int n = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) n += __popcll(__ballot(key[j] >= t));
-        if (n >= rank) cur = t;
-    }
-    const float a = __uint_as_float((cur & 0x80000000u) ? (cur & 0x7fffffffu) : ~cur);      // -inf when fewer than `rank` entries exist
-    if (lane == 0) thr[q] = a > -INFINITY ? a - 2.f * eps[q] : -INFINITY;
-}
+// (A one-wave-per-query form -- the <= 1024 sample entries in 16 registers per lane, the rank by a 32-step binary search on the keys with
+// ballot counts, no LDS -- was built in round 5 and measured at 15.0 us against this kernel's 11.6 for 1024 queries: one wave walks
+// its dependent chain of loads and 32 search steps alone, where this one puts four waves on a query.  Removed.)
 
 template <bool STAGED>
 __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
@@ -3304,14 +3276,9 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             else if (rsc == 2) hipLaunchKernelGGL(k_knn_hi_sample<2>, sg, sb, lds, st, sp);
             else hipLaunchKernelGGL(k_knn_hi_sample<3>, sg, sb, lds, st, sp);
             const int n_ent = sp.n_splits * KW_SAMPLE_LIST;
-            if (n_ent <= 1024)
-                hipLaunchKernelGGL(k_floor_from_sample_w, dim3((unsigned)ceil_div64(nq, RF_THREADS / 64)), dim3(RF_THREADS), 0, st, (const float*)sp.part_score,
-                                   (const int*)sp.part_idx, n_ent, k + margin, (const float*)eps, thr_init, nq, live_nr > 0 ? ps : (float*)nullptr, emit_cap,
-                                   live_nr > 0 ? flag_count + KNN_PROG_OFF : (int*)nullptr, n_qtiles);
-            else
-                hipLaunchKernelGGL(k_floor_from_sample, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)n_ent * 4 + 1040, st, (const float*)sp.part_score,
-                                   (const int*)sp.part_idx, n_ent, k + margin, (const float*)eps, thr_init, live_nr > 0 ? ps : (float*)nullptr, emit_cap,
-                                   live_nr > 0 ? flag_count + KNN_PROG_OFF : (int*)nullptr, n_qtiles);
+            hipLaunchKernelGGL(k_floor_from_sample, dim3((unsigned)nq), dim3(RF_THREADS), (size_t)n_ent * 4 + 1040, st, (const float*)sp.part_score,
+                               (const int*)sp.part_idx, n_ent, k + margin, (const float*)eps, thr_init, live_nr > 0 ? ps : (float*)nullptr, emit_cap,
+                               live_nr > 0 ? flag_count + KNN_PROG_OFF : (int*)nullptr, n_qtiles);
             wp.thr_init = thr_init;
         }
         const dim3 b(KW_THREADS);
