@@ -120,7 +120,7 @@ def main():
                          "DFT-as-GEMM on the f16 matrix pipe (k_logmel_h_clip), for A/B")
     ap.add_argument("--live-floor", type=int, choices=[0, 1], default=0,
                     help="0 (default) = the tile scan runs one launch per phase with k_kth_floor between them; 1 = ONE launch that raises its "
-                         "admission floors inside it (round 5; measured 1-4 %% slower: gpurun_out/r5_ab*.txt), for A/B")
+                         "admission floors inside it (round 5; measured 1-4 %% slower: profiles/r5_ab_*.txt), for A/B")
     ap.add_argument("--store-dtype", choices=["f32", "f16"], default="f32",
                     help="f16 = the reference's use_float16 knob (fp16 rows); NOT the headline configuration")
     ap.add_argument("--embed-dtype", choices=["f32", "bf16"], default="f32",

@@ -2323,7 +2323,7 @@ struct radad_knn_s {
     int opt_dense = 1;           // stores of <= RF_STAGE_MAX rows: all scores + select (k_knn_dense) instead of the register-list kernels
     size_t last_o_cnt = 0, last_o_thr = 0; int64_t last_emit_nq = 0;   // the last tile-scan search's candidate counters / floors in the workspace
     int opt_live_floor = 0;      // 1: the tile scan covers the store in ONE launch and raises its admission floors inside it; 0 (default): one
-                                 // launch per phase.  Measured on one box, three alternations (gpurun_out/r5_ab*.txt): the one-launch form is
+                                 // launch per phase.  Measured on one box, three alternations (profiles/r5_ab_*.txt): the one-launch form is
                                  // 1 % slower in the scan at 1 M x 512 (0.862-0.872 against 0.853-0.860 ms; the step equal within noise: it
                                  // saves k_kth_floor), 1.4 % at 10 M x 512, 4 % at 50 M x 256 -- ~0.2-0.3 us per tile for the progress atomic
                                  // and the floor reload, which go to memory past the L2s; the ramps and tails it removes are smaller than that
@@ -3291,7 +3291,7 @@ static int knn_search_phase1(radad_knn_t h, const void* q_in, int q_dtype, int64
             rp.n = r1 - r0; rp.id_off = r0;
             rp.loose_floor = (r0 == 0 && r1 == h->ntotal && s_splits < KW_SAMPLE_SPLITS && live_nr == 0) ? 1 : 0;      // one launch behind a small sample
             // (the counting form for the FIRST phase of a large store -- its floor is the sample's, ~64 candidates per tile -- was measured
-            // too: 0.883-0.887 against 0.874-0.877 ms per search, three alternations on one box, gpurun_out/r5_ab.txt of that run: no)
+            // too: 0.883-0.887 against 0.874-0.877 ms per search, three alternations on one box, profiles/r5_ab_counting_emit_phase0.txt: no)
             if (live_nr > 0) {
                 rp.floor_live = thr_init; rp.eps = eps; rp.k_sel = k;
                 for (int i = 0; i < 4; ++i) rp.prog_thr[i] = live_at[i];

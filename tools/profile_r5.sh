@@ -49,8 +49,8 @@ for m in cosine ip l2; do python tools/exp_scan.py --metric $m --reps 20 2> /dev
 for w in 2 4 8; do python tools/rehearse_rank.py --world $w 2> /dev/null; done > gpurun_out/${T}_rehearse.txt; echo rehearse
 python tools/bench_fullstore.py --config 4 > gpurun_out/${T}_config4_full.json 2> /dev/null
 python tools/bench_fullstore.py --config 5 > gpurun_out/${T}_config5_full.json 2> /dev/null; echo fullstore
-python bench.py --live-floor 0 --cpu-sample 0 --cpu-baseline-clips 0 --pcie 0 --sustain 0 --unstructured 0 > gpurun_out/${T}_bench_launch_per_phase.json 2> /dev/null
-python bench.py --live-floor 0 --db-rows 100000 --cpu-sample 0 --cpu-baseline-clips 0 --pcie 0 --sustain 0 --unstructured 0 > gpurun_out/${T}_bench_config2_launch_per_phase.json 2> /dev/null; echo ab2
+python bench.py --live-floor 1 --cpu-sample 0 --cpu-baseline-clips 0 --pcie 0 --sustain 0 --unstructured 0 > gpurun_out/${T}_bench_one_launch.json 2> /dev/null
+python bench.py --live-floor 1 --db-rows 100000 --cpu-sample 0 --cpu-baseline-clips 0 --pcie 0 --sustain 0 --unstructured 0 > gpurun_out/${T}_bench_config2_one_launch.json 2> /dev/null; echo ab2
 python tools/bench_ivf.py > gpurun_out/${T}_ivf.json 2> /dev/null
 python tools/bench_ivf.py 1,256,1024 0 > gpurun_out/${T}_ivf_f32_lists.json 2> /dev/null; echo ivf
 for f in default ragged config2 f16 bf16_f16 scan_f32 logmel_gemm; do python - <<PY
