@@ -2657,17 +2657,24 @@ static void knn_geometry_wide(int64_t n, int64_t nq, int* n_qtiles, int* n_split
     want = std::max<int64_t>(8, ceil_div64(want, 8) * 8);
     want = std::min<int64_t>(want, 1024);
     int64_t tiles_per = ceil_div64(tiles, want);
-    // Two rounds of workgroups are as good as one only while the chunks are long: a launch takes (rounds of 256 workgroups) x (tiles
-    // per chunk) tile times, and with a handful of tiles per chunk the rounding of the second factor decides -- BASELINE config 2's
-    // 100 k rows are 391 tiles x 4 query tiles: 128 chunks of 4 tiles = 392 workgroups = 2 rounds x 4 = 8 tile times, 64 chunks of 7 =
-    // 224 workgroups = ONE round of 7 (1 M rows: 2 x 31 = 1 x 62, the two-round form stays).  One round is taken when it is
-    // strictly cheaper by that count.
+    // A launch takes (rounds of 256 workgroups) x (tiles per chunk) tile times, and both factors round up.  Round 4 always took
+    // ceil(512 / query tiles) chunks ("two rounds keep the tail short"): right for 4 query tiles x 1 M rows (2 x 31 = 1 x 62), wrong
+    // where the rounding bites -- BASELINE config 2's 100 k rows = 391 tiles x 4 query tiles: 128 chunks of 4 tiles = 392 workgroups =
+    // 2 rounds x 4 = 8 tile times, 64 chunks of 7 = 224 workgroups = ONE round of 7; configs 4 / 5 at full size, 40 query tiles: 16
+    // chunks = 640 workgroups = 2.5 -> 3 rounds x 2442 tiles, 32 chunks = 1280 = exactly 5 rounds x 1221 (-17 %).  So: the cheapest by
+    // that count among one round's worth of chunks and `want`, `want` + 8, ... 4 x `want`, when it saves 3 % or more.
     if (qt <= 256) {
-        auto cost = [&](int64_t splits, int64_t per) { return ceil_div64((int64_t)qt * ceil_div64(tiles, per), 256) * per; };
-        int64_t one = std::max<int64_t>(8, (256 / qt) / 8 * 8);
-        one = std::min<int64_t>(one, want);
-        const int64_t per_one = ceil_div64(tiles, one);
-        if (one < want && cost(one, per_one) < cost(want, tiles_per)) { want = one; tiles_per = per_one; }
+        auto cost = [&](int64_t per) { return ceil_div64((int64_t)qt * ceil_div64(tiles, per), 256) * per; };
+        int64_t best = want, best_per = tiles_per, best_cost = cost(tiles_per);
+        auto consider = [&](int64_t splits) {
+            splits = std::min<int64_t>(std::max<int64_t>(8, splits / 8 * 8), std::min<int64_t>(1024, std::max<int64_t>(8, ceil_div64(tiles, 8) * 8)));
+            const int64_t per = ceil_div64(tiles, splits);
+            const int64_t c = cost(per);
+            if (c * 100 < best_cost * 97) { best = splits; best_per = per; best_cost = c; }      // (a gain under 3 % is not worth leaving two rounds)
+        };
+        consider(256 / qt);
+        for (int64_t sp = want + 8; sp <= 4 * want; sp += 8) consider(sp);
+        want = best; tiles_per = best_per;
     }
     *n_qtiles = qt;
     *n_splits = (int)want;
