@@ -46,7 +46,8 @@ python tools/exp_scan.py --rows 25423 --dim 5376 --nq 256 --k 15 --metric l2 --r
 python tools/exp_scan.py --rows 25423 --dim 5376 --nq 256 --k 15 --metric cosine --reps 20 >> gpurun_out/${T}_refshape_scan.txt 2> /dev/null
 python tools/exp_scan.py --rows 25423 --dim 3584 --nq 256 --k 15 --metric l2 --reps 20 >> gpurun_out/${T}_refshape_scan.txt 2> /dev/null
 for m in cosine ip l2; do python tools/exp_scan.py --metric $m --reps 20 2> /dev/null; done > gpurun_out/${T}_scan_unstructured.txt; echo scans
-for w in 2 4 8; do python tools/rehearse_rank.py --world $w 2> /dev/null; done > gpurun_out/${T}_rehearse.txt; echo rehearse
+for w in 2 4 8; do python tools/rehearse_rank.py --world $w 2> /dev/null; done > gpurun_out/${T}_rehearse.txt
+for w in 2 4 8; do python tools/rehearse_rank.py --world $w --plant all 2> /dev/null; done > gpurun_out/${T}_rehearse_plant_all.txt; echo rehearse
 python tools/bench_fullstore.py --config 4 > gpurun_out/${T}_config4_full.json 2> /dev/null
 python tools/bench_fullstore.py --config 5 > gpurun_out/${T}_config5_full.json 2> /dev/null; echo fullstore
 python bench.py --live-floor 1 --cpu-sample 0 --cpu-baseline-clips 0 --pcie 0 --sustain 0 --unstructured 0 > gpurun_out/${T}_bench_one_launch.json 2> /dev/null

@@ -15,6 +15,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--rank", type=int, default=0)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--plant", choices=["rank0", "all"], default="rank0",
+                help="rank0 (bench.py since round 5): the store holds near-duplicates of rank 0's 1024 clips only -- the same store for every N; "
+                     "all (rounds 3-4): of every rank's clips -- planted rows, and with them every rank's candidates, grow with N")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 lib = _lib.load()
@@ -33,14 +36,16 @@ Q = a.world * B
 lo, hi = shard_bounds(N, a.world, a.rank)
 rows = torch.empty((hi - lo, D), device=dev)
 _lib.check(lib.radad_synth_rows(rows.data_ptr(), lo, hi - lo, D, 4321, 0, _lib.stream_ptr(dev)))
-noise = torch.empty((2 * Q, D), device=dev)
-_lib.check(lib.radad_synth_rows(noise.data_ptr(), 0, 2 * Q, D, 99, 0, _lib.stream_ptr(dev)))
-jj = torch.arange(Q, device=dev)
-scale = all_emb.norm(dim=1, keepdim=True) / (D ** 0.5)
+P = Q if a.plant == "all" else B                      # clips that have planted near-duplicates in the store
+noise = torch.empty((2 * P, D), device=dev)
+_lib.check(lib.radad_synth_rows(noise.data_ptr(), 0, 2 * P, D, 99, 0, _lib.stream_ptr(dev)))
+jj = torch.arange(P, device=dev)
+pemb = all_emb[:P]
+scale = pemb.norm(dim=1, keepdim=True) / (D ** 0.5)
 for c, eps in ((0, 0.05), (1, 0.10)):
     g = (jj * 977 + c * 350003 + 17) % N
     mine = (g >= lo) & (g < hi)
-    rows[g[mine] - lo] = all_emb[mine] + eps * scale[mine] * noise[c * Q:(c + 1) * Q][mine]
+    rows[g[mine] - lo] = pemb[mine] + eps * scale[mine] * noise[c * P:(c + 1) * P][mine]
 idx = R.HipFlatIndex(D, _lib.METRIC_COSINE, 0, id_base=lo)
 idx.add_device(rows)
 # the bound the OTHER shards would contribute to the all-reduce: their search_begin over their rows (built one after the other here)
@@ -56,7 +61,7 @@ if ap_bound:
         for c, eps in ((0, 0.05), (1, 0.10)):
             g = (jj * 977 + c * 350003 + 17) % N
             mine = (g >= l2_) & (g < h2_)
-            orow[g[mine] - l2_] = all_emb[mine] + eps * scale[mine] * noise[c * Q:(c + 1) * Q][mine]
+            orow[g[mine] - l2_] = pemb[mine] + eps * scale[mine] * noise[c * P:(c + 1) * P][mine]
         other = R.HipFlatIndex(D, _lib.METRIC_COSINE, 0, id_base=l2_)
         other.add_device(orow)
         lb = other.search_begin(all_emb, K)
@@ -91,7 +96,7 @@ for bound in ((False, True) if ap_bound else (False,)):
     t1.record(); torch.cuda.synchronize()
     ms = idx.profile_read()
     la = idx.last_launch()
-    print(json.dumps({"world": a.world, "rank": a.rank, "rows": hi - lo, "queries": Q, "global_bound": bound,
+    print(json.dumps({"world": a.world, "rank": a.rank, "plant": a.plant, "rows": hi - lo, "queries": Q, "global_bound": bound,
                       "scan_ms": round(float(np.mean(ms)) * la["scan_launches"], 4), "rerank_ms": round(float(np.mean([x.elapsed_time(y) for x, y in evs])), 4),
                       "search_ms": round(t0.elapsed_time(t1) / a.reps, 4),
                       "candidates_per_query": round(la["certificate"]["candidates_rescored"] / Q, 1), "launch": la}))
