@@ -56,3 +56,45 @@ for name, fn in (("sequential", lambda s: sequential(s)), ("two streams", lambda
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 40
     print(f"{name:36s} {dt * 1e3:.4f} ms per step  {B / dt / 1e3:.1f} k clips/s")
+
+
+# ---- the front-end of one sub-batch beside the projection of another -- two extractor handles (each owns its log-mel
+# scratch), half a batch each, on two streams: k_logmel_fft_clip (vector ALU) of one half could run beside k_proj_pool2 (matrix pipe) of
+# the other IF both fit a CU at once.  They do not: 237 + 2 x 242 VGPRs per SIMD lane-row against 512; this measures it.
+fe2 = R.MelProjectionFeatureExtractor(cfg)
+H = B // 2
+w1, w2 = wave[:H * 64000], wave[H * 64000:]
+o_h = np.arange(H + 1, dtype=np.int64) * 64000
+
+
+def embed_whole(steps):
+    for _ in range(steps):
+        fe.embed_clips(wave, offs)
+
+
+def embed_halves_one_stream(steps):
+    for _ in range(steps):
+        fe.embed_clips(w1, o_h); fe2.embed_clips(w2, o_h)
+
+
+def embed_halves_two_streams(steps):
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur); s2.wait_stream(cur)
+    for _ in range(steps):
+        with torch.cuda.stream(s1):
+            fe.embed_clips(w1, o_h)
+        with torch.cuda.stream(s2):
+            fe2.embed_clips(w2, o_h)
+    cur.wait_stream(s1); cur.wait_stream(s2)
+
+
+for name, fn in (("embed, whole batch", embed_whole), ("embed, two halves, one stream", embed_halves_one_stream),
+                 ("embed, two halves, two streams", embed_halves_two_streams), ("embed, whole batch", embed_whole)):
+    fn(5)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn(40)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 40
+    print(f"{name:36s} {dt * 1e3:.4f} ms per {B} clips")
