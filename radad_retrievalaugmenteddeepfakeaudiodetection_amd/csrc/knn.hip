@@ -1347,6 +1347,11 @@ __global__ __launch_bounds__(RF_THREADS) void k_merge_refine(RefineParams p) {
         else a_k = radix_select_kth(e_sc, NE, p.k, hist, w_pt);
         if (a_k > -INFINITY) tau = a_k - two_eps;                        // (fewer than k listed rows: tau stays -inf, all of them go on)
     }
+    // (Round 5, measured and reverted: halving the band.  tau = a_k - 2 eps pays eps twice; scoring the <= 32 rows with a >= a_k in fp32
+    // first gives L = the k-th largest of their s - e, a lower bound of the exact k-th best, and only rows with a + eps >= L can be
+    // among the exact k best.  On the benchmark's store that cut the re-scored rows from 151 to 105 per query -- and the kernel went
+    // from 73 to 79 us: one more dependent stage per workgroup costs more than the 30 % of row reads it saves; this kernel is bound
+    // by its chain of dependent round trips, not by bytes.)
     // sharded search: no row whose score is below (the best lower bound any shard has of the exact k-th best) - eps can be in the
     // GLOBAL top-k, whatever this shard's own k-th best is -- the re-rank takes only what can still matter
     if (cert && p.global_lb) tau = fmaxf(tau, p.global_lb[q] - 0.5f * two_eps);
