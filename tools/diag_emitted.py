@@ -1,3 +1,5 @@
+"""Diagnosis (not product): candidates emitted per query and per query tile by the tile scan on a config-5-sized store, both scan forms
+(radad_knn_last_emitted) -- how the round dependence of the first one-launch form was found.  usage: python tools/diag_emitted.py [rows]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
