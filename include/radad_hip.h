@@ -187,6 +187,10 @@ int radad_knn_last_launch(radad_knn_t h, int* n_query_tiles, int* n_db_splits, i
 int radad_knn_last_scan_kind(radad_knn_t h, int* kind);
 /* scan-kernel launches of the last search (the certified tile scan covers a large store in two: the first eighth with the
  * sample's admission floor, the rest with the floor the first eighth's candidates give); radad_knn_profile_read has one entry each */
+/* How ONE launch of the certified tile scan over n_rows rows and n_queries queries is laid out (pure host arithmetic, no device): 256-query
+ * tiles, `chunks` row chunks (a multiple of 8) of rows_per_chunk rows (a multiple of the 256-row tile) -- query_tiles x chunks workgroups.
+ * Chosen by what the launch costs: (rounds of 256 workgroups) x (tiles per chunk), both rounded up. */
+int radad_knn_scan_geometry(int64_t n_rows, int64_t n_queries, int* query_tiles, int* chunks, int64_t* rows_per_chunk);
 int radad_knn_last_scan_launches(radad_knn_t h, int* n_launches);
 /* phases of the last search's tile scan: 1 + the number of times the admission floors were raised from the candidates emitted so far --
  * between launches (the default: 2 up to ~1.2 M rows, 3 up to ~9.5 M, 4 beyond) or inside the one launch (RADAD_KNN_OPT_LIVE_FLOOR 1) */

@@ -74,6 +74,7 @@ SIGNATURES = {
     "radad_knn_search_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
     "radad_knn_search_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "radad_knn_search_abort": (C.c_int, [C.c_void_p]),
+    "radad_knn_scan_geometry": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
     "radad_knn_last_scan_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_last_scan_phases": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "radad_knn_last_emitted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),

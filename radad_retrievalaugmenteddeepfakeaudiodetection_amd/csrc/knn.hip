@@ -3795,6 +3795,12 @@ int radad_knn_last_emitted(radad_knn_t h, int* counts_host, float* floors_host, 
     return RADAD_OK;
 }
 
+int radad_knn_scan_geometry(int64_t n_rows, int64_t n_queries, int* query_tiles, int* chunks, int64_t* rows_per_chunk) {
+    RADAD_REQUIRE(n_rows >= 1 && n_queries >= 1 && query_tiles && chunks && rows_per_chunk, "radad_knn_scan_geometry: bad argument");
+    knn_geometry_wide(n_rows, n_queries, query_tiles, chunks, rows_per_chunk);
+    return RADAD_OK;
+}
+
 int radad_knn_last_scan_phases(radad_knn_t h, int* n_phases) {
     RADAD_REQUIRE(h && n_phases, "NULL argument");
     std::lock_guard<std::mutex> lk(h->mu);

@@ -262,3 +262,36 @@ def test_clip_chunking_covers_every_frame_once_and_fits_the_planes():
     _lib.check(lib.radad_embed_clip_chunks(0, 200, 100, out))
     assert list(out) == [0, 0, 0, 0, 0]
     assert lib.radad_embed_clip_chunks(3, 4, 2, out) == _lib.RADAD_EINVAL               # fewer than 8 frames per segment: not this path
+
+
+def test_scan_geometry_is_chosen_by_cost():
+    """radad_knn_scan_geometry (host arithmetic of the tile scan's launch, no device): chunks are whole tiles and cover the store; the
+    launch never costs more (rounds of 256 workgroups x tiles per chunk) than round 4's fixed two rounds' worth of chunks; and the cases
+    the choice was made for: BASELINE config 2 runs ONE round, configs 4 / 5 at full size exactly five."""
+    lib = _lib.load()
+
+    def geo(n, nq):
+        qt, ch, rows = C.c_int(), C.c_int(), C.c_int64()
+        _lib.check(lib.radad_knn_scan_geometry(n, nq, C.byref(qt), C.byref(ch), C.byref(rows)))
+        return qt.value, ch.value, rows.value
+
+    def cost(n, qt, rows):
+        tiles, per = -(-n // 256), rows // 256
+        return -(-(qt * -(-tiles // per)) // 256) * per
+
+    def old(n, nq):                                   # round 4: ceil(512 / query tiles) chunks, rounded up to a multiple of 8
+        qt, tiles = -(-nq // 256), -(-n // 256)
+        want = min(max(8, -(-min(-(-512 // qt), tiles) // 8) * 8), 1024)
+        return qt, want, -(-tiles // want) * 256
+
+    for n, nq in ((100_000, 1024), (1_000_000, 1024), (25_423, 256), (1_300_000, 700), (10_000_000, 10_240), (50_000_000, 10_240),
+                  (20_000, 300), (125_000, 8192), (200_000, 512), (1_000_000, 256), (1_250_000, 10_240), (16_384, 17), (999_937, 1023)):
+        qt, ch, rows = geo(n, nq)
+        assert qt == -(-nq // 256) and ch % 8 == 0 and ch >= 8 and rows % 256 == 0 and ch * rows >= n, (n, nq, qt, ch, rows)
+        oq, och, orows = old(n, nq)
+        assert cost(n, qt, rows) <= cost(n, oq, orows), (n, nq, (qt, ch, rows), (oq, och, orows))
+    assert geo(100_000, 1024) == (4, 64, 7 * 256)                      # config 2: 224 workgroups, one round of 7 tiles (was 2 x 4)
+    assert geo(1_000_000, 1024) == (4, 128, 31 * 256)                  # the headline: two rounds of 31 (one of 62 costs the same)
+    assert geo(10_000_000, 10_240) == (40, 32, 1221 * 256)             # config 4: 1280 workgroups = 5 rounds (was 640 = 2.5 -> 3)
+    assert geo(50_000_000, 10_240)[1] == 32
+    assert lib.radad_knn_scan_geometry(0, 1, None, None, None) == _lib.RADAD_EINVAL
